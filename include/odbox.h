@@ -1,0 +1,104 @@
+/*
+ * odbox -- C-ABI of the MI355X (gfx950) box-processing library, libodbox.so.
+ *
+ * The reference (bioothod/object_detection) has no FFI of its own: the path sits behind
+ * plain Python module functions on tf.Tensor.  Each entry point below names
+ * the reference function (file:line under the reference tree) whose arithmetic it replaces;
+ * object_detection_amd/{anchors,bndbox}.py bind them with ctypes under the reference's own
+ * Python signatures.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch-ROCm storage) unless noted;
+ *     row-major, fp32 / int32 / int8, caller owns every buffer;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*, NULL = default stream)
+ *     and the call returns without synchronising; no allocation happens inside;
+ *   - return 0 on success, a negative ODBOX_E* code on failure; odbox_last_error() returns
+ *     the calling thread's last message; no C++ exception crosses the boundary;
+ *   - safe to call concurrently from several host threads on different streams.
+ */
+#ifndef ODBOX_H
+#define ODBOX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ODBOX_VERSION 100            /* 0.1.0 */
+#define ODBOX_EINVAL (-1)            /* bad argument (shape, NULL, limit exceeded) */
+#define ODBOX_EHIP   (-2)            /* a HIP runtime call failed */
+#define ODBOX_ENOSPC (-3)            /* workspace too small */
+
+#define ODBOX_MAX_CLASSES   4096     /* class id is 12 bits of the candidate key */
+#define ODBOX_MAX_ANCHORS   1048576  /* anchor id is 20 bits of the candidate key */
+#define ODBOX_MAX_RET       4096     /* kept list of one (image, class) lives in LDS */
+
+int odbox_version(void);
+const char *odbox_last_error(void);
+
+/* anchors.py:44-87 AnchorGenerator.tile_anchors_over_feature_map:
+ * out[(i*fw + j)*A + a] = base[a] + ((j+.5)*stride, (i+.5)*stride, (j+.5)*stride, (i+.5)*stride). */
+int odbox_anchor_tile(const float *base /*[A,4]*/, int A, int fh, int fw, float stride,
+                      float *out /*[fh*fw*A,4]*/, void *stream);
+
+/* anchors.py:116-213 anchor_targets_bbox, with compute_gt_annotations (:215-274),
+ * bndbox.py:254-299 bbox_overlap and anchors.py:277-299 bbox_transform fused.
+ * out_regression [B,N,5] and out_labels [B,N,C+1] are the reference's two return values;
+ * out_match_idx (argmax GT per anchor), out_state (-1 ignore / 0 background / 1 foreground)
+ * and out_max_iou are compact side outputs.  Any out_* may be NULL (skipped); gt_labels may
+ * be NULL when out_labels is NULL.  img_h / img_w = +inf disables the out-of-image test
+ * (that is compute_gt_annotations on its own). */
+int odbox_match_encode(const float *anchors /*[N,4]*/, const float *gt_boxes /*[B,G,4]*/,
+                       const int32_t *gt_labels /*[B,G]*/, int B, int N, int G, int C,
+                       float img_h, float img_w, float neg_thr, float pos_thr,
+                       float *out_regression /*[B,N,5]*/, float *out_labels /*[B,N,C+1]*/,
+                       int32_t *out_match_idx /*[B,N]*/, int8_t *out_state /*[B,N]*/,
+                       float *out_max_iou /*[B,N]*/, void *stream);
+
+/* bndbox.py:254-299 bbox_overlap: dense [B,N,G] IoU, -1 for padded GT rows.
+ * anchors_batched != 0: anchors is [B,N,4]; else [N,4] shared by every image. */
+int odbox_bbox_overlap(const float *anchors, const float *gt_boxes /*[B,G,4]*/, int B, int N, int G,
+                       int anchors_batched, float *out_iou /*[B,N,G]*/, void *stream);
+
+/* anchors.py:277-299 bbox_transform: anchors [N,4] (anchors_batched == 0) or [B,N,4]. */
+int odbox_bbox_transform(const float *anchors, int anchors_batched, const float *gt_boxes /*[B,N,4]*/,
+                         int B, int N, float *out /*[B,N,4]*/, void *stream);
+
+/* bndbox.py:71-99 regress_bndboxes: boxes [N,4] (boxes_batched == 0) or [B,N,4]. */
+int odbox_regress_boxes(const float *boxes, int boxes_batched, const float *regressors /*[B,N,4]*/,
+                        int B, int N, float *out /*[B,N,4]*/, void *stream);
+
+/* bndbox.py:102-115 clip_boxes: x in [0, img_w-1], y in [0, img_h-1]; n boxes, may be in place. */
+int odbox_clip_boxes(const float *boxes /*[n,4]*/, size_t n, float img_h, float img_w,
+                     float *out /*[n,4]*/, void *stream);
+
+/* bndbox.py:10-41 scale_boxes (divide == 0: x*fx, y*fy) and bndbox.py:44-68
+ * normalize_bndboxes (divide != 0: x/fx, y/fy). */
+int odbox_scale_boxes(const float *boxes /*[n,4]*/, size_t n, float fx, float fy, int divide,
+                      float *out /*[n,4]*/, void *stream);
+
+/* Bytes of device workspace odbox_decode_nms needs for these sizes (0 on bad arguments). */
+size_t odbox_decode_nms_workspace(int B, int N, int C, int max_ret, int pre_nms_topk);
+
+/* encoder.py:200-214 inference tail = bndbox.py:71-99 regress_bndboxes -> :102-115 clip_boxes
+ * -> :117-252 nms (class argmax, score filter, per-class tf.image.non_max_suppression, concat,
+ * top_k, zero pad).  anchors == NULL: regress_or_boxes already holds decoded boxes (the plain
+ * bndbox.nms entry).  pre_nms_topk == 0 is the reference's unbounded behaviour; > 0 keeps the
+ * best pre_nms_topk candidates per image by (score desc, anchor asc) before the class
+ * partition (a documented extension, no counterpart in the reference).
+ * out_keep_anchor [B,max_ret] (anchor id of every detection, -1 padding) and out_count [B]
+ * may be NULL.  workspace must be 256-byte aligned. */
+int odbox_decode_nms(const float *anchors /*[N,4] or NULL*/, const float *regress_or_boxes /*[B,N,4]*/,
+                     const float *scores /*[B,N,C]*/, int B, int N, int C,
+                     float img_h, float img_w, int do_clip,
+                     float score_thr, float iou_thr, int max_ret, int pre_nms_topk,
+                     float *out_boxes /*[B,max_ret,4]*/, float *out_scores /*[B,max_ret]*/,
+                     int32_t *out_labels /*[B,max_ret]*/, int32_t *out_keep_anchor /*[B,max_ret]*/,
+                     int32_t *out_count /*[B]*/, void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODBOX_H */

@@ -1,0 +1,83 @@
+"""ctypes binding of libodbox.so (include/odbox.h).  There is no CPU fallback: if the HIP
+library is missing or no GPU is present every compute entry raises."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libodbox.so')
+
+_lib = None
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/odbox.h one to one
+SIGNATURES = {
+    'odbox_version': (_i, []),
+    'odbox_last_error': (ctypes.c_char_p, []),
+    'odbox_anchor_tile': (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),
+    'odbox_match_encode': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'odbox_bbox_overlap': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'odbox_bbox_transform': (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
+    'odbox_regress_boxes': (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
+    'odbox_clip_boxes': (_i, [_vp, _sz, _f, _f, _vp, _vp]),
+    'odbox_scale_boxes': (_i, [_vp, _sz, _f, _f, _i, _vp, _vp]),
+    'odbox_decode_nms_workspace': (_sz, [_i, _i, _i, _i, _i]),
+    'odbox_decode_nms': (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _f, _i, _i,
+                              _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+}
+
+
+class OdboxError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libodbox.so and declare every prototype.  Needs no GPU."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OdboxError(
+                'libodbox.so is not built (%s); run `python -m object_detection_amd.build`. '
+                'There is no CPU fallback.' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise OdboxError('no ROCm GPU visible: odbox kernels are HIP-only, there is no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().odbox_last_error()
+        raise OdboxError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def as_dev(x, dtype, device):
+    """torch tensor / numpy array / nested list -> contiguous 16-byte-aligned device tensor."""
+    if not isinstance(x, torch.Tensor):
+        x = torch.as_tensor(x)
+    x = x.to(device=device, dtype=dtype, non_blocking=True).contiguous()
+    if x.data_ptr() % 16:
+        x = x.clone()
+    return x

@@ -1,0 +1,169 @@
+"""Drop-in for the reference module `anchors` (anchors.py) on MI355X.
+
+Same names, argument order, defaults and return order as the reference; tensors are torch
+tensors on the current ROCm device instead of tf.Tensor (NumPy arrays and CPU tensors are
+accepted and uploaded).  All arithmetic runs in hand-written HIP kernels through the C-ABI of
+include/odbox.h -- there is no CPU fallback, every call raises OdboxError without a GPU.
+"""
+import math
+import typing
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import AnchorsConfig
+
+_INF = float('inf')
+
+
+class AnchorGenerator(object):
+    """anchors.py:22-114.  `anchors` ([A,4] fp32, A = 3*len(aspect_ratios)) is computed on the
+    host in float64 and rounded to fp32 last, exactly like the reference's NumPy code; tiling
+    over a feature map is the HIP kernel `odbox_anchor_tile`."""
+
+    def __init__(self, size: float, aspect_ratios: typing.Sequence[float], stride: int = 1):
+        self.size = size
+        self.stride = stride
+        self.aspect_ratios = aspect_ratios
+        self.anchor_scales = [2 ** 0, 2 ** (1 / 3.0), 2 ** (2 / 3.0)]
+        self.anchors = self._generate()
+        self._dev_cache = {}
+
+    def __len__(self):
+        return len(self.aspect_ratios) * len(self.anchor_scales)
+
+    def __call__(self, *args, **kwargs):
+        return self.tile_anchors_over_feature_map(*args, **kwargs)
+
+    def _generate(self) -> torch.Tensor:
+        # anchor a: ratio a // 3 (h / w), scale a % 3; equal-area boxes centred on the origin
+        rows = []
+        n_scales = len(self.anchor_scales)
+        for a in range(len(self)):
+            ratio = float(self.aspect_ratios[a // n_scales])
+            side = self.size * self.anchor_scales[a % n_scales]
+            w = math.sqrt((side * side) / ratio)
+            h = w * ratio
+            rows.append((0.0 - w * 0.5, 0.0 - h * 0.5, w - w * 0.5, h - h * 0.5))
+        return torch.from_numpy(np.asarray(rows, dtype=np.float64).astype(np.float32))
+
+    def tile_anchors_over_feature_map(self, feature_map_shape) -> torch.Tensor:
+        """[H*W*A, 4] fp32 xyxy; cell (i, j) -> rows (i*W + j)*A .. +A (anchors.py:47-87)."""
+        lib = _lib.load()
+        dev = _lib.require_gpu()
+        fh, fw = int(feature_map_shape[0]), int(feature_map_shape[1])
+        base = self._dev_cache.get(dev)
+        if base is None:
+            base = self._dev_cache[dev] = _lib.as_dev(self.anchors, torch.float32, dev)
+        out = torch.empty((fh * fw * len(self), 4), dtype=torch.float32, device=dev)
+        _lib.check(lib.odbox_anchor_tile(_lib.ptr(base), len(self), fh, fw, float(self.stride),
+                                         _lib.ptr(out), _lib.stream_ptr()), 'odbox_anchor_tile')
+        return out
+
+
+def generate_anchors(anchors_config: AnchorsConfig, im_shape: int) -> torch.Tensor:
+    """detection.py:223-236: P3..P7 generators, feature side im_shape // 2**level, concat."""
+    parts = []
+    for level in range(3, 8):
+        gen = AnchorGenerator(size=anchors_config.sizes[level - 3],
+                              aspect_ratios=anchors_config.ratios,
+                              stride=anchors_config.strides[level - 3])
+        side = im_shape // (2 ** level)
+        parts.append(gen((side, side, 3)))
+    return torch.cat(parts, dim=0)
+
+
+def _image_hw(images):
+    """The reference reads only tf.shape(images)[1:3] (anchors.py:164-167).  Accept a tensor /
+    array of shape [B,H,W,C], or the shape itself, or (H, W)."""
+    shape = tuple(images.shape) if hasattr(images, 'shape') else tuple(images)
+    if len(shape) == 2:
+        return float(shape[0]), float(shape[1])
+    if len(shape) == 4:
+        return float(shape[1]), float(shape[2])
+    raise ValueError('images must be [B,H,W,C] (or its shape, or (H, W)); got %r' % (shape,))
+
+
+def match_encode(anchors, image_hw, bndboxes, labels, num_classes,
+                 negative_overlap=0.4, positive_overlap=0.5,
+                 dense=True, compact=False):
+    """Fused matcher + encoder (`odbox_match_encode`).  Returns a dict with `regression`
+    [B,N,5] / `labels` [B,N,C+1] when dense, and `match_idx` i32 / `state` i8 / `max_iou` f32
+    [B,N] when compact."""
+    lib = _lib.load()
+    dev = _lib.require_gpu()
+    anchors = _lib.as_dev(anchors, torch.float32, dev)
+    bndboxes = _lib.as_dev(bndboxes, torch.float32, dev)      # fp16 GT is cast (anchors.py:251)
+    if anchors.dim() != 2 or anchors.shape[1] != 4:
+        raise ValueError('anchors must be [N,4]')
+    if bndboxes.dim() != 3 or bndboxes.shape[2] != 4:
+        raise ValueError('bndboxes must be [B,G,4]')
+    B, G = int(bndboxes.shape[0]), int(bndboxes.shape[1])
+    N = int(anchors.shape[0])
+    C = int(num_classes)
+    if labels is not None:
+        labels = _lib.as_dev(labels, torch.int32, dev)
+        if tuple(labels.shape) != (B, G):
+            raise ValueError('labels must be [B,G]')
+    out = {}
+    reg = lab = midx = state = miou = None
+    if dense:
+        reg = out['regression'] = torch.empty((B, N, 5), dtype=torch.float32, device=dev)
+        lab = out['labels'] = torch.empty((B, N, C + 1), dtype=torch.float32, device=dev)
+    if compact:
+        midx = out['match_idx'] = torch.empty((B, N), dtype=torch.int32, device=dev)
+        state = out['state'] = torch.empty((B, N), dtype=torch.int8, device=dev)
+        miou = out['max_iou'] = torch.empty((B, N), dtype=torch.float32, device=dev)
+    _lib.check(lib.odbox_match_encode(
+        _lib.ptr(anchors), _lib.ptr(bndboxes), _lib.ptr(labels), B, N, G, C,
+        float(image_hw[0]), float(image_hw[1]), float(negative_overlap), float(positive_overlap),
+        _lib.ptr(reg), _lib.ptr(lab), _lib.ptr(midx), _lib.ptr(state), _lib.ptr(miou),
+        _lib.stream_ptr()), 'odbox_match_encode')
+    return out
+
+
+def anchor_targets_bbox(anchors, images, bndboxes, labels, num_classes: int,
+                        negative_overlap: float = 0.4, positive_overlap: float = 0.5,
+                        dtype=torch.float32) -> typing.Tuple[torch.Tensor, torch.Tensor]:
+    """anchors.py:116-213.  Returns (regression [B,N,5], labels [B,N,num_classes+1]) -- in that
+    order, like the reference's return statement (:213; its docstring has them swapped).
+    Last column of both: anchor state -1 ignore / 0 background / 1 foreground.
+    `dtype` only casts the image height/width in the reference; fp32 here as there."""
+    r = match_encode(anchors, _image_hw(images), bndboxes, labels, num_classes,
+                     negative_overlap, positive_overlap, dense=True, compact=False)
+    return r['regression'], r['labels']
+
+
+def compute_gt_annotations(anchors, annotations, negative_overlap=0.4, positive_overlap=0.5):
+    """anchors.py:215-274 -> (positive [B,N] bool, ignore [B,N] bool, batched_indices [B*N,2] i32).
+    Pure per-anchor argmax + two thresholds, no out-of-image test, no per-GT forced match."""
+    r = match_encode(anchors, (_INF, _INF), annotations, None, 1,
+                     negative_overlap, positive_overlap, dense=False, compact=True)
+    state = r['state']
+    B, N = state.shape
+    positive = state == 1
+    ignore = state == -1
+    bidx = torch.arange(B, dtype=torch.int32, device=state.device).repeat_interleave(N)
+    batched = torch.stack([bidx, r['match_idx'].reshape(-1)], dim=1)
+    return positive, ignore, batched
+
+
+def bbox_transform(anchors, gt_boxes) -> torch.Tensor:
+    """anchors.py:277-299: anchors [N,4] or [B,N,4], gt_boxes [B,N,4] (or [N,4]) -> offsets."""
+    lib = _lib.load()
+    dev = _lib.require_gpu()
+    anchors = _lib.as_dev(anchors, torch.float32, dev)
+    gt = _lib.as_dev(gt_boxes, torch.float32, dev)
+    squeeze = gt.dim() == 2
+    if squeeze:
+        gt = gt.unsqueeze(0)
+    B, N = int(gt.shape[0]), int(gt.shape[1])
+    batched = anchors.dim() == 3
+    if anchors.shape[-2] != N or (batched and anchors.shape[0] != B):
+        raise ValueError('anchors %r do not broadcast against gt_boxes %r'
+                         % (tuple(anchors.shape), tuple(gt.shape)))
+    out = torch.empty_like(gt)
+    _lib.check(lib.odbox_bbox_transform(_lib.ptr(anchors), int(batched), _lib.ptr(gt), B, N,
+                                        _lib.ptr(out), _lib.stream_ptr()), 'odbox_bbox_transform')
+    return out[0] if squeeze else out

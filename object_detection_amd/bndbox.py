@@ -1,0 +1,162 @@
+"""Drop-in for the reference module `bndbox` (bndbox.py) on MI355X.
+
+Same names, argument order, defaults, return order and padding conventions as the reference;
+torch tensors on the current ROCm device instead of tf.Tensor.  HIP kernels only (C-ABI of
+include/odbox.h), no CPU fallback.
+"""
+from typing import Tuple
+
+import torch
+
+from . import _lib
+
+_ws_cache = {}
+
+
+def _boxes2(boxes, dev):
+    boxes = _lib.as_dev(boxes, torch.float32, dev)
+    if boxes.dim() != 2 or boxes.shape[1] != 4:
+        raise ValueError('boxes must be [n,4]')
+    return boxes
+
+
+def scale_boxes(boxes, from_size: Tuple[int, int], to_size: Tuple[int, int]) -> torch.Tensor:
+    """bndbox.py:10-41: x * (from_w / to_w), y * (from_h / to_h); sizes are (height, width)."""
+    lib = _lib.load()
+    dev = _lib.require_gpu()
+    boxes = _boxes2(boxes, dev)
+    out = torch.empty_like(boxes)
+    _lib.check(lib.odbox_scale_boxes(_lib.ptr(boxes), boxes.shape[0],
+                                     from_size[1] / to_size[1], from_size[0] / to_size[0], 0,
+                                     _lib.ptr(out), _lib.stream_ptr()), 'odbox_scale_boxes')
+    return out
+
+
+def normalize_bndboxes(boxes, image_size: Tuple[int, int]) -> torch.Tensor:
+    """bndbox.py:44-68: x / (w - 1), y / (h - 1); image_size is (height, width)."""
+    lib = _lib.load()
+    dev = _lib.require_gpu()
+    boxes = _boxes2(boxes, dev)
+    h, w = image_size
+    out = torch.empty_like(boxes)
+    _lib.check(lib.odbox_scale_boxes(_lib.ptr(boxes), boxes.shape[0], float(w - 1), float(h - 1), 1,
+                                     _lib.ptr(out), _lib.stream_ptr()), 'odbox_scale_boxes')
+    return out
+
+
+def regress_bndboxes(boxes, regressors) -> torch.Tensor:
+    """bndbox.py:71-99.  boxes [B,N,4] (the reference's tiled anchors) or [N,4] (shared by all
+    images, no tile needed); regressors [B,N,4] -> [B,N,4]."""
+    lib = _lib.load()
+    dev = _lib.require_gpu()
+    boxes = _lib.as_dev(boxes, torch.float32, dev)
+    reg = _lib.as_dev(regressors, torch.float32, dev)
+    if reg.dim() != 3 or reg.shape[2] != 4:
+        raise ValueError('regressors must be [B,N,4]')
+    B, N = int(reg.shape[0]), int(reg.shape[1])
+    batched = boxes.dim() == 3
+    if boxes.shape[-1] != 4 or boxes.shape[-2] != N or (batched and boxes.shape[0] != B):
+        raise ValueError('boxes %r do not match regressors %r' % (tuple(boxes.shape), tuple(reg.shape)))
+    out = torch.empty_like(reg)
+    _lib.check(lib.odbox_regress_boxes(_lib.ptr(boxes), int(batched), _lib.ptr(reg), B, N,
+                                       _lib.ptr(out), _lib.stream_ptr()), 'odbox_regress_boxes')
+    return out
+
+
+def clip_boxes(boxes, im_size: Tuple[int, int]) -> torch.Tensor:
+    """bndbox.py:102-115: x in [0, w-1], y in [0, h-1]; im_size is (height, width)."""
+    lib = _lib.load()
+    dev = _lib.require_gpu()
+    boxes = _lib.as_dev(boxes, torch.float32, dev)
+    if boxes.shape[-1] != 4:
+        raise ValueError('boxes must be [...,4]')
+    h, w = im_size
+    out = torch.empty_like(boxes)
+    _lib.check(lib.odbox_clip_boxes(_lib.ptr(boxes), boxes.numel() // 4, float(h), float(w),
+                                    _lib.ptr(out), _lib.stream_ptr()), 'odbox_clip_boxes')
+    return out
+
+
+def bbox_overlap(bboxes, gt_bboxes) -> torch.Tensor:
+    """bndbox.py:254-299: bboxes [B,N,4] (or [N,4] shared), gt_bboxes [B,G,4] -> IoU [B,N,G],
+    -1 for padded (all-negative) GT rows."""
+    lib = _lib.load()
+    dev = _lib.require_gpu()
+    bb = _lib.as_dev(bboxes, torch.float32, dev)
+    gt = _lib.as_dev(gt_bboxes, torch.float32, dev)
+    if gt.dim() != 3 or gt.shape[2] != 4:
+        raise ValueError('gt_bboxes must be [B,G,4]')
+    B, G = int(gt.shape[0]), int(gt.shape[1])
+    batched = bb.dim() == 3
+    N = int(bb.shape[-2])
+    if bb.shape[-1] != 4 or (batched and bb.shape[0] != B):
+        raise ValueError('bboxes %r do not match gt_bboxes %r' % (tuple(bb.shape), tuple(gt.shape)))
+    out = torch.empty((B, N, G), dtype=torch.float32, device=dev)
+    _lib.check(lib.odbox_bbox_overlap(_lib.ptr(bb), _lib.ptr(gt), B, N, G, int(batched),
+                                      _lib.ptr(out), _lib.stream_ptr()), 'odbox_bbox_overlap')
+    return out
+
+
+def _workspace(lib, dev, B, N, C, max_ret, topk):
+    need = lib.odbox_decode_nms_workspace(B, N, C, max_ret, topk)
+    if need == 0:
+        raise _lib.OdboxError('odbox_decode_nms_workspace: unsupported sizes B=%d N=%d C=%d max_ret=%d'
+                              % (B, N, C, max_ret))
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _ws_cache[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+    return ws
+
+
+def _decode_nms(anchors, regress_or_boxes, class_scores, im_size, do_clip,
+                score_threshold, iou_threshold, max_ret, pre_nms_topk, extras):
+    lib = _lib.load()
+    dev = _lib.require_gpu()
+    rb = _lib.as_dev(regress_or_boxes, torch.float32, dev)
+    sc = _lib.as_dev(class_scores, torch.float32, dev)
+    if sc.dim() != 3 or rb.dim() != 3 or rb.shape[2] != 4 or rb.shape[:2] != sc.shape[:2]:
+        raise ValueError('need boxes/regressors [B,N,4] and class_scores [B,N,C]; got %r, %r'
+                         % (tuple(rb.shape), tuple(sc.shape)))
+    B, N, C = (int(v) for v in sc.shape)
+    if anchors is not None:
+        anchors = _lib.as_dev(anchors, torch.float32, dev)
+        if tuple(anchors.shape) != (N, 4):
+            raise ValueError('anchors must be [N,4]')
+    max_ret = int(max_ret)
+    boxes = torch.empty((B, max_ret, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((B, max_ret), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, max_ret), dtype=torch.int32, device=dev)
+    keep = torch.empty((B, max_ret), dtype=torch.int32, device=dev) if extras else None
+    count = torch.empty((B,), dtype=torch.int32, device=dev) if extras else None
+    if B > 0:
+        ws = _workspace(lib, dev, B, N, C, max_ret, int(pre_nms_topk))
+        h, w = (float(im_size[0]), float(im_size[1])) if im_size is not None else (0.0, 0.0)
+        _lib.check(lib.odbox_decode_nms(
+            _lib.ptr(anchors), _lib.ptr(rb), _lib.ptr(sc), B, N, C, h, w, int(bool(do_clip)),
+            float(score_threshold), float(iou_threshold), max_ret, int(pre_nms_topk),
+            _lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(labels), _lib.ptr(keep), _lib.ptr(count),
+            _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), 'odbox_decode_nms')
+    if extras:
+        return boxes, scores, labels, keep, count
+    return boxes, scores, labels
+
+
+def nms(bboxes, class_scores, score_threshold: float = 0.3, iou_threshold: float = 0.45,
+        max_ret: int = 100, pre_nms_topk: int = 0, return_keep: bool = False):
+    """bndbox.py:117-252.  bboxes [B,N,4] xyxy, class_scores [B,N,C] ->
+    (boxes [B,max_ret,4] xyxy, scores [B,max_ret], labels [B,max_ret] int32), score-sorted,
+    zero-padded (pad score 0, pad label 0).  Each box gets ONE class (argmax), per-class greedy
+    NMS keeps at most max_ret per class, then the global top max_ret.
+    return_keep=True also returns (keep_anchor [B,max_ret] i32 with -1 padding, count [B])."""
+    return _decode_nms(None, bboxes, class_scores, None, False, score_threshold, iou_threshold,
+                       max_ret, pre_nms_topk, return_keep)
+
+
+def decode_and_nms(anchors, regressors, class_scores, im_size, score_threshold: float = 0.3,
+                   iou_threshold: float = 0.45, max_ret: int = 100, pre_nms_topk: int = 0,
+                   return_keep: bool = False):
+    """The inference tail of EfnDet.call (encoder.py:200-214) in one call: anchors [N,4] are
+    broadcast over the batch (no tile), regress -> clip to im_size=(h, w) -> nms."""
+    return _decode_nms(anchors, regressors, class_scores, im_size, True, score_threshold,
+                       iou_threshold, max_ret, pre_nms_topk, return_keep)

@@ -1,0 +1,85 @@
+"""Multi-GPU plumbing: one process per GPU, images sharded by batch index, ONE all-gather of
+fixed-size detection records per eval batch (RCCL over xGMI when the backend is "nccl").
+
+The reference has no counterpart: under Horovod every rank evaluates the whole eval set on
+its own (detection.py:333 shards only the training files) and runs COCOeval locally
+(evaluate.py:164-190).  Match+encode needs no collective -- targets feed the local loss shard.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun) and pin
+    this rank to GPU LOCAL_RANK.  Returns (rank, world_size).  No-op for a single process."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % torch.cuda.device_count())
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        kwargs = {}
+        if backend == 'nccl':
+            kwargs['device_id'] = torch.device('cuda', torch.cuda.current_device())
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+    return rank, world
+
+
+def shard_range(batch, rank, world):
+    """Contiguous image range [lo, hi) of `rank`; the batch is cut into `world` equal slices of
+    ceil(batch / world) images, trailing slices may be short or empty."""
+    per = (batch + world - 1) // world
+    lo = min(rank * per, batch)
+    return lo, min(lo + per, batch)
+
+
+def pack_detections(boxes, scores, labels):
+    """[b,R,4] f32, [b,R] f32, [b,R] i32 -> [b,R,6] f32 records (label bit-cast, not converted)."""
+    return torch.cat([boxes, scores.unsqueeze(-1), labels.view(torch.float32).unsqueeze(-1)], dim=-1)
+
+
+def unpack_detections(records):
+    boxes = records[..., 0:4].contiguous()
+    scores = records[..., 4].contiguous()
+    labels = records[..., 5].contiguous().view(torch.int32)
+    return boxes, scores, labels
+
+
+def gather_detections(boxes, scores, labels, batch=None, group=None):
+    """All ranks pass the detections of their shard ([b,R,4], [b,R], [b,R] with b =
+    ceil(batch / world), short shards zero-padded here) and get the whole batch back, images in
+    rank order: one all_gather_into_tensor of [b,R,6] records."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return boxes, scores, labels
+    world = dist.get_world_size(group)
+    rec = pack_detections(boxes, scores, labels)
+    if batch is not None:
+        per = (batch + world - 1) // world
+        if rec.shape[0] < per:
+            pad = torch.zeros((per - rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
+            rec = torch.cat([rec, pad], dim=0)
+    rec = rec.contiguous()
+    out = torch.empty((world * rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
+    dist.all_gather_into_tensor(out, rec, group=group)
+    if batch is not None:
+        out = out[:batch]
+    return unpack_detections(out)
+
+
+def sharded_decode_and_nms(anchors, regressors, class_scores, im_size, **kw):
+    """Every rank holds the full batch inputs (or at least its own slice filled in), computes
+    decode + NMS for its slice only and all-gathers the records."""
+    from . import bndbox
+    if not (dist.is_available() and dist.is_initialized()):
+        return bndbox.decode_and_nms(anchors, regressors, class_scores, im_size, **kw)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    B = regressors.shape[0]
+    lo, hi = shard_range(B, rank, world)
+    b, s, l = bndbox.decode_and_nms(anchors, regressors[lo:hi], class_scores[lo:hi], im_size, **kw)
+    return gather_detections(b, s, l, batch=B)

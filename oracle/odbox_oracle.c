@@ -1,0 +1,296 @@
+/*
+ * CPU oracle, C restatement of the box-processing hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load the
+ * library built from this file (oracle/_build/libodbox_oracle.so).  The product library
+ * (object_detection_amd/csrc -> libodbox.so) never links or calls it.
+ *
+ * PARITY UNPINNED: the reference has no tests or golden vectors for this path and
+ * TensorFlow cannot be run here.  This file restates the reference's op
+ * sequences in scalar fp32 (build with -ffp-contract=off so no op is fused) and the
+ * published behaviour of the TF kernels it calls.  It is cross-checked against the NumPy
+ * restatement oracle/odbox_oracle.py and the hand-derived known answers in tests/.
+ *
+ * Reference citations are file:line under /root/reference.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static inline float fmaxf_(float a, float b) { return a > b ? a : b; }   /* inputs are finite */
+static inline float fminf_(float a, float b) { return a < b ? a : b; }
+
+/* anchors.py:60-87 : cell k = i*fw + j ; out[k*A + a] = base[a] + (sx, sy, sx, sy) */
+void odbox_oracle_anchor_tile(const float *base, int A, int fh, int fw, float stride, float *out)
+{
+    for (int i = 0; i < fh; ++i) {
+        float sy = ((float)i + 0.5f) * stride;
+        for (int j = 0; j < fw; ++j) {
+            float sx = ((float)j + 0.5f) * stride;
+            float *o = out + ((size_t)(i * fw + j) * A) * 4;
+            for (int a = 0; a < A; ++a) {
+                o[a * 4 + 0] = base[a * 4 + 0] + sx;
+                o[a * 4 + 1] = base[a * 4 + 1] + sy;
+                o[a * 4 + 2] = base[a * 4 + 2] + sx;
+                o[a * 4 + 3] = base[a * 4 + 3] + sy;
+            }
+        }
+    }
+}
+
+/* bndbox.py:273-297 for one (anchor, gt) pair */
+static inline float overlap_pair(const float *a, const float *g)
+{
+    float ix0 = fmaxf_(a[0], g[0]);
+    float ix1 = fminf_(a[2], g[2]);
+    float iy0 = fmaxf_(a[1], g[1]);
+    float iy1 = fminf_(a[3], g[3]);
+    float iw = fmaxf_(ix1 - ix0, 0.0f);
+    float ih = fmaxf_(iy1 - iy0, 0.0f);
+    float i_area = iw * ih;
+    float a_area = (a[3] - a[1]) * (a[2] - a[0]);
+    float g_area = (g[3] - g[1]) * (g[2] - g[0]);
+    float u = ((a_area + g_area) - i_area) + 1e-8f;
+    float iou = i_area / u;
+    float gmax = fmaxf_(fmaxf_(g[0], g[1]), fmaxf_(g[2], g[3]));
+    return gmax < 0.0f ? -1.0f : iou;
+}
+
+/* bndbox.py:254-299 ; anchors_batched = 0 -> anchors [N,4] shared by all images */
+void odbox_oracle_bbox_overlap(const float *anchors, const float *gt, int B, int N, int G,
+                               int anchors_batched, float *out)
+{
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < N; ++n) {
+            const float *a = anchors + ((size_t)(anchors_batched ? b : 0) * N + n) * 4;
+            for (int g = 0; g < G; ++g)
+                out[((size_t)b * N + n) * G + g] = overlap_pair(a, gt + ((size_t)b * G + g) * 4);
+        }
+}
+
+/*
+ * anchors.py:116-213 (anchor_targets_bbox) with compute_gt_annotations (:215-274) and
+ * bbox_transform (:277-299) folded in.  Every out_* pointer may be NULL.
+ */
+void odbox_oracle_match_encode(const float *anchors, const float *gt_boxes, const int32_t *gt_labels,
+                               int B, int N, int G, int C, float img_h, float img_w,
+                               float neg_thr, float pos_thr,
+                               float *out_regression, float *out_labels, int32_t *out_match_idx,
+                               int8_t *out_state, float *out_max_iou, int threads)
+{
+#ifdef _OPENMP
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+#endif
+    for (int b = 0; b < B; ++b) {
+        const float *gtb = gt_boxes + (size_t)b * G * 4;
+        const int32_t *glb = gt_labels ? gt_labels + (size_t)b * G : NULL;
+        for (int n = 0; n < N; ++n) {
+            const float *a = anchors + (size_t)n * 4;
+            /* tf.argmax / tf.reduce_max (anchors.py:255-256): first maximal index */
+            int best = 0;
+            float best_iou = 0.0f;
+            for (int g = 0; g < G; ++g) {
+                float v = overlap_pair(a, gtb + (size_t)g * 4);
+                if (g == 0 || v > best_iou) { best = g; best_iou = v; }
+            }
+            int positive = best_iou >= pos_thr;                                  /* :267 */
+            int ignore = ((best_iou > neg_thr) && !positive) || (best_iou < 0.0f); /* :270-272 */
+            float xc = (a[0] + a[2]) / 2.0f;                                     /* :178-184 */
+            float yc = (a[1] + a[3]) / 2.0f;
+            ignore = ignore || (xc >= img_w) || (yc >= img_h);
+            float state = ignore ? -1.0f : (positive ? 1.0f : 0.0f);             /* :206-207 */
+            size_t row = (size_t)b * N + n;
+            if (out_labels) {                                                    /* :187-196,210 */
+                float *o = out_labels + row * (size_t)(C + 1);
+                int lab = (positive && glb) ? glb[best] : -1;
+                if (ignore) lab = -1;
+                for (int c = 0; c < C; ++c) o[c] = (c == lab) ? 1.0f : 0.0f;
+                o[C] = state;
+            }
+            if (out_regression) {                                                /* :199-202,211 */
+                const float *g = gtb + (size_t)best * 4;
+                float aw = a[2] - a[0];
+                float ah = a[3] - a[1];
+                float *o = out_regression + row * 5;
+                o[0] = (((g[0] - a[0]) / aw) - 0.0f) / 0.2f;
+                o[1] = (((g[1] - a[1]) / ah) - 0.0f) / 0.2f;
+                o[2] = (((g[2] - a[2]) / aw) - 0.0f) / 0.2f;
+                o[3] = (((g[3] - a[3]) / ah) - 0.0f) / 0.2f;
+                o[4] = state;
+            }
+            if (out_match_idx) out_match_idx[row] = best;
+            if (out_state) out_state[row] = (int8_t)state;
+            if (out_max_iou) out_max_iou[row] = best_iou;
+        }
+    }
+}
+
+/* bndbox.py:88-99 */
+static inline void decode_box(const float *a, const float *r, float *o)
+{
+    float w = a[2] - a[0];
+    float h = a[3] - a[1];
+    o[0] = a[0] + (r[0] * 0.2f + 0.0f) * w;
+    o[1] = a[1] + (r[1] * 0.2f + 0.0f) * h;
+    o[2] = a[2] + (r[2] * 0.2f + 0.0f) * w;
+    o[3] = a[3] + (r[3] * 0.2f + 0.0f) * h;
+}
+
+/* bndbox.py:105-115 */
+static inline void clip_box(float *o, float img_h, float img_w)
+{
+    float hi_x = img_w - 1.0f, hi_y = img_h - 1.0f;
+    o[0] = fminf_(fmaxf_(o[0], 0.0f), hi_x);
+    o[1] = fminf_(fmaxf_(o[1], 0.0f), hi_y);
+    o[2] = fminf_(fmaxf_(o[2], 0.0f), hi_x);
+    o[3] = fminf_(fmaxf_(o[3], 0.0f), hi_y);
+}
+
+void odbox_oracle_regress_boxes(const float *boxes, int boxes_batched, const float *regress,
+                                int B, int N, float *out)
+{
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < N; ++n)
+            decode_box(boxes + ((size_t)(boxes_batched ? b : 0) * N + n) * 4,
+                       regress + ((size_t)b * N + n) * 4, out + ((size_t)b * N + n) * 4);
+}
+
+void odbox_oracle_clip_boxes(const float *boxes, size_t n, float img_h, float img_w, float *out)
+{
+    for (size_t i = 0; i < n; ++i) {
+        float t[4];
+        memcpy(t, boxes + i * 4, sizeof t);
+        clip_box(t, img_h, img_w);
+        memcpy(out + i * 4, t, sizeof t);
+    }
+}
+
+/* TF NonMaxSuppressionV3 IoU (third-party), boxes in xyxy here: min/max
+ * normalisation makes the corner order irrelevant. */
+static inline float nms_iou(const float *p, const float *q)
+{
+    float px0 = fminf_(p[0], p[2]), px1 = fmaxf_(p[0], p[2]);
+    float py0 = fminf_(p[1], p[3]), py1 = fmaxf_(p[1], p[3]);
+    float qx0 = fminf_(q[0], q[2]), qx1 = fmaxf_(q[0], q[2]);
+    float qy0 = fminf_(q[1], q[3]), qy1 = fmaxf_(q[1], q[3]);
+    float pa = (py1 - py0) * (px1 - px0);
+    float qa = (qy1 - qy0) * (qx1 - qx0);
+    if (pa <= 0.0f || qa <= 0.0f) return 0.0f;
+    float ih = fmaxf_(fminf_(py1, qy1) - fmaxf_(py0, qy0), 0.0f);
+    float iw = fmaxf_(fminf_(px1, qx1) - fmaxf_(px0, qx0), 0.0f);
+    float inter = ih * iw;
+    return inter / ((pa + qa) - inter);
+}
+
+typedef struct { float score; int32_t anchor; int32_t label; int32_t pos; } cand_t;
+
+/* (label asc, score desc, anchor asc): per-class NMS visiting order */
+static int cmp_class_score(const void *x, const void *y)
+{
+    const cand_t *a = (const cand_t *)x, *b = (const cand_t *)y;
+    if (a->label != b->label) return a->label < b->label ? -1 : 1;
+    if (a->score != b->score) return a->score > b->score ? -1 : 1;
+    return a->anchor < b->anchor ? -1 : (a->anchor > b->anchor);
+}
+
+/* tf.math.top_k(sorted=True): score desc, ties -> lower concatenated position */
+static int cmp_score_pos(const void *x, const void *y)
+{
+    const cand_t *a = (const cand_t *)x, *b = (const cand_t *)y;
+    if (a->score != b->score) return a->score > b->score ? -1 : 1;
+    return a->pos < b->pos ? -1 : (a->pos > b->pos);
+}
+
+/*
+ * encoder.py:200-214 + bndbox.py:117-252.  anchors == NULL: `regress_or_boxes` already holds
+ * decoded boxes (the plain bndbox.nms entry).  Returns 0, or -1 if out of memory.
+ */
+int odbox_oracle_decode_nms(const float *anchors, const float *regress_or_boxes, const float *scores,
+                            int B, int N, int C, float img_h, float img_w, int do_clip,
+                            float score_thr, float iou_thr, int max_ret,
+                            float *out_boxes, float *out_scores, int32_t *out_labels,
+                            int32_t *out_keep_anchor, int32_t *out_count, int threads)
+{
+    int failed = 0;
+#ifdef _OPENMP
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+#endif
+    for (int b = 0; b < B; ++b) {
+        float *ob = out_boxes + (size_t)b * max_ret * 4;
+        float *os = out_scores + (size_t)b * max_ret;
+        int32_t *ol = out_labels + (size_t)b * max_ret;
+        memset(ob, 0, sizeof(float) * 4 * max_ret);                   /* bndbox.py:237-244 */
+        memset(os, 0, sizeof(float) * max_ret);
+        memset(ol, 0, sizeof(int32_t) * max_ret);
+        if (out_keep_anchor)
+            for (int k = 0; k < max_ret; ++k) out_keep_anchor[(size_t)b * max_ret + k] = -1;
+        if (out_count) out_count[b] = 0;
+
+        cand_t *cand = (cand_t *)malloc(sizeof(cand_t) * (size_t)(N > 0 ? N : 1));
+        float *cbox = (float *)malloc(sizeof(float) * 4 * (size_t)(N > 0 ? N : 1));
+        if (!cand || !cbox) { free(cand); free(cbox); failed = 1; continue; }
+        int m = 0;
+        for (int n = 0; n < N; ++n) {                                  /* bndbox.py:153-154,205 */
+            const float *s = scores + ((size_t)b * N + n) * C;
+            int lab = 0;
+            float best = s[0];
+            for (int c = 1; c < C; ++c)
+                if (s[c] > best) { best = s[c]; lab = c; }
+            if (!(best > score_thr)) continue;
+            cand[m].score = best; cand[m].anchor = n; cand[m].label = lab; cand[m].pos = 0;
+            ++m;
+        }
+        for (int i = 0; i < m; ++i) {
+            const float *src = regress_or_boxes + ((size_t)b * N + cand[i].anchor) * 4;
+            float *dst = cbox + (size_t)cand[i].anchor * 4;
+            if (anchors) decode_box(anchors + (size_t)cand[i].anchor * 4, src, dst);
+            else memcpy(dst, src, sizeof(float) * 4);
+            if (do_clip) clip_box(dst, img_h, img_w);
+        }
+        qsort(cand, (size_t)m, sizeof(cand_t), cmp_class_score);
+        /* greedy per-class NMS, kept entries compacted to the front of cand[] in
+         * (class asc, selection order) = the reference's TensorArray concat order */
+        int total = 0;
+        for (int s0 = 0; s0 < m;) {
+            int s1 = s0;
+            while (s1 < m && cand[s1].label == cand[s0].label) ++s1;
+            int seg_begin = total;
+            for (int i = s0; i < s1 && total - seg_begin < max_ret; ++i) {
+                int keep = 1;
+                for (int k = seg_begin; k < total; ++k)
+                    if (nms_iou(cbox + (size_t)cand[i].anchor * 4,
+                                cbox + (size_t)cand[k].anchor * 4) > iou_thr) { keep = 0; break; }
+                if (keep) { cand[total] = cand[i]; cand[total].pos = total; ++total; }
+            }
+            s0 = s1;
+        }
+        qsort(cand, (size_t)total, sizeof(cand_t), cmp_score_pos);     /* bndbox.py:225 */
+        int k = total < max_ret ? total : max_ret;
+        for (int r = 0; r < k; ++r) {
+            memcpy(ob + (size_t)r * 4, cbox + (size_t)cand[r].anchor * 4, sizeof(float) * 4);
+            os[r] = cand[r].score;
+            ol[r] = cand[r].label;
+            if (out_keep_anchor) out_keep_anchor[(size_t)b * max_ret + r] = cand[r].anchor;
+        }
+        if (out_count) out_count[b] = k;
+        free(cand);
+        free(cbox);
+    }
+    return failed ? -1 : 0;
+}
+
+int odbox_oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,204 @@
+"""Known-answer tests of the CPU oracle (hand-derived) and cross-check of its two
+independent restatements (NumPy, C).  The reference holds no fixtures for this path, so these
+are what pins the oracle ("parity unpinned" against the reference itself)."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from oracle import odbox_oracle as O
+
+F = np.float32
+
+
+def test_base_anchor_table_size32():
+    a = O.base_anchors(32, (1, 2, .5))
+    assert a.shape == (9, 4) and a.dtype == np.float32
+    np.testing.assert_array_equal(a[0], F([-16, -16, 16, 16]))
+    np.testing.assert_allclose(a[1], [-20.158737, -20.158737, 20.158737, 20.158737], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(a[2], [-25.398417, -25.398417, 25.398417, 25.398417], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(a[3], [-11.313708, -22.627417, 11.313708, 22.627417], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(a[8], [-35.918785, -17.959393, 35.918785, 17.959393], rtol=0, atol=3e-6)
+
+
+@pytest.mark.parametrize('S,N', [(512, 49104), (1024, 196416)])
+def test_generate_anchors_counts_and_corners(S, N):
+    a = O.generate_anchors(S)
+    assert a.shape == (N, 4)
+    np.testing.assert_array_equal(a[0], F([-12, -12, 20, 20]))
+    if S == 512:
+        np.testing.assert_allclose(a[-1], [-126.70056, 160.64972, 1022.70056, 735.3503], rtol=1e-6)
+    xc = (a[:, 0] + a[:, 2]) / 2
+    yc = (a[:, 1] + a[:, 3]) / 2
+    assert (xc < S).all() and (yc < S).all()
+
+
+def test_yolo_shaped_grid():
+    assert O.yolo_shaped_anchors(416).shape == (10647, 4)
+
+
+def test_tile_order_y_outer_x_inner():
+    base = O.base_anchors(32, [1])
+    t = O.tile_anchors(base, 2, 3, 8)
+    assert t.shape == (2 * 3 * 3, 4)
+    # cell (i=0, j=1) -> rows 3..5, shifted by (12, 4)
+    np.testing.assert_array_equal(t[3], base[0] + F([12, 4, 12, 4]))
+    # cell (i=1, j=0) -> rows 9..11, shifted by (4, 12)
+    np.testing.assert_array_equal(t[9], base[0] + F([4, 12, 4, 12]))
+    np.testing.assert_array_equal(t, c_oracle.anchor_tile(base, 2, 3, 8))
+
+
+def _iou(a, g):
+    return O.bbox_overlap(F(a).reshape(1, 1, 4), F(g).reshape(1, 1, 4))[0, 0, 0]
+
+
+def test_iou_known_answers():
+    assert _iou([0, 0, 10, 10], [0, 0, 10, 10]) == F(1.0)
+    assert _iou([0, 0, 10, 10], [20, 20, 30, 30]) == F(0.0)
+    assert _iou([0, 0, 10, 10], [5, 0, 15, 10]) == F(50.0) / F(150.0)
+    assert _iou([0, 0, 10, 10], [5, 0, 15, 10]) == F(0.33333334)
+    assert _iou([0, 0, 10, 10], [-1, -1, -1, -1]) == F(-1.0)
+
+
+def _targets(anchors, gt, labels, C=3, hw=(512, 512)):
+    return O.anchor_targets_bbox(F(anchors), hw, F(gt)[None], np.asarray(labels, np.int32)[None], C)
+
+
+def test_threshold_edges():
+    anchors = [[0, 0, 10, 10]]
+    # IoU exactly 0.5 -> positive (>=)
+    r = _targets(anchors, [[0, 0, 10, 5]], [2])
+    assert r['state'][0, 0] == 1 and r['labels'][0, 0].tolist() == [0, 0, 1, 1]
+    # IoU 0.4f is not > 0.4f -> background
+    r = _targets(anchors, [[0, 0, 10, 4]], [2])
+    assert r['max_iou'][0, 0] == F(0.4) and r['state'][0, 0] == 0
+    assert r['labels'][0, 0].tolist() == [0, 0, 0, 0]
+    # IoU in (0.4, 0.5) -> ignore
+    r = _targets(anchors, [[0, 0, 10, 4.5]], [2])
+    assert r['state'][0, 0] == -1 and r['labels'][0, 0].tolist() == [0, 0, 0, -1]
+
+
+def test_ties_and_padding():
+    anchors = [[0, 0, 10, 10], [100, 100, 110, 110]]
+    gt = [[0, 0, 10, 10], [0, 0, 10, 10], [-1, -1, -1, -1]]
+    r = _targets(anchors, gt, [1, 2, -1])
+    assert r['match_idx'][0].tolist() == [0, 0]          # identical rows: lower index; no overlap: 0
+    assert r['state'][0].tolist() == [1, 0]
+    assert r['labels'][0, 0].tolist() == [0, 1, 0, 1]
+    # all rows padded: argmax 0, max -1, every anchor ignored, one-hot all zero
+    r = _targets(anchors, [[-1] * 4] * 3, [-1] * 3)
+    assert r['match_idx'][0].tolist() == [0, 0]
+    assert (r['max_iou'][0] == -1).all() and (r['state'][0] == -1).all()
+    assert (r['labels'][0, :, :3] == 0).all() and (r['labels'][0, :, 3] == -1).all()
+
+
+def test_out_of_image_anchor_is_ignored():
+    anchors = [[500, 10, 530, 40]]           # centre x = 515 >= 512
+    r = _targets(anchors, [[500, 10, 530, 40]], [0])
+    assert r['max_iou'][0, 0] == F(1.0) and r['state'][0, 0] == -1
+    r = _targets(anchors, [[500, 10, 530, 40]], [0], hw=(512, 600))
+    assert r['state'][0, 0] == 1
+
+
+def test_encode_known_answer_and_decode_inverse():
+    a = F([[0, 0, 10, 20]])
+    g = F([[[1, 2, 11, 18]]])
+    t = O.bbox_transform(a[None], g)
+    np.testing.assert_allclose(t[0, 0], [0.5, 0.5, 0.5, -0.5], rtol=1e-6)
+    back = O.regress_bndboxes(a[None], t)
+    np.testing.assert_allclose(back[0, 0], g[0, 0], rtol=1e-6)
+
+
+def test_returns_regression_for_every_anchor():
+    # negatives / ignored / padded matches still get offsets (anchors.py:199-202)
+    r = _targets([[0, 0, 10, 10]], [[-1, -1, -1, -1]], [-1])
+    np.testing.assert_allclose(r['regression'][0, 0, :4], [-0.5, -0.5, -5.5, -5.5], rtol=1e-6)
+    assert r['regression'][0, 0, 4] == -1
+
+
+def test_clip():
+    b = F([[[-5, -1, 600, 511.5]]])
+    np.testing.assert_array_equal(O.clip_boxes(b, (512, 512))[0, 0], F([0, 0, 511, 511]))
+
+
+def _nms1(boxes, scores, **kw):
+    return O.nms(F(boxes)[None], F(scores)[None], **kw)
+
+
+def test_nms_known_answers():
+    box = [0, 0, 10, 10]
+    # duplicates, same class -> one kept; lower anchor index first on equal score
+    b, s, l, k, n = _nms1([box, box], [[0.9, 0.1], [0.9, 0.1]])
+    assert n[0] == 1 and k[0, 0] == 0 and l[0, 0] == 0 and s[0, 0] == F(0.9)
+    assert (s[0, 1:] == 0).all() and (l[0, 1:] == 0).all() and (b[0, 1:] == 0).all() and (k[0, 1:] == -1).all()
+    # duplicates in different classes -> both kept, top_k tie -> lower class first
+    b, s, l, k, n = _nms1([box, box], [[0.9, 0.1], [0.1, 0.9]])
+    assert n[0] == 2 and l[0, :2].tolist() == [0, 1] and k[0, :2].tolist() == [0, 1]
+    # score == threshold -> dropped
+    b, s, l, k, n = _nms1([box], [[0.3, 0.1]])
+    assert n[0] == 0 and (s == 0).all()
+    # IoU exactly == threshold -> kept (suppress only when strictly greater): 50/100 = 0.5
+    b, s, l, k, n = _nms1([[0, 0, 10, 10], [0, 0, 10, 5]], [[0.9], [0.8]], iou_threshold=0.5)
+    assert n[0] == 2
+    b, s, l, k, n = _nms1([[0, 0, 10, 10], [0, 0, 10, 5]], [[0.9], [0.8]], iou_threshold=0.49)
+    assert n[0] == 1
+    # zero-area box never suppresses nor is suppressed
+    b, s, l, k, n = _nms1([[5, 5, 5, 9], [5, 5, 5, 9]], [[0.9], [0.8]])
+    assert n[0] == 2
+    # no detections -> all zero
+    b, s, l, k, n = _nms1([box], [[0.1, 0.2]])
+    assert n[0] == 0 and (b == 0).all() and (s == 0).all() and (l == 0).all()
+
+
+def test_nms_per_class_truncation_then_global_topk():
+    # 6 disjoint boxes in class 0 and 2 in class 1; max_ret 3 -> per class cap 3, then top 3 overall
+    boxes = [[20 * i, 0, 20 * i + 10, 10] for i in range(8)]
+    scores = [[0.50 + 0.01 * i, 0] for i in range(6)] + [[0, 0.95], [0, 0.40]]
+    b, s, l, k, n = _nms1(boxes, scores, max_ret=3)
+    assert n[0] == 3
+    assert k[0].tolist() == [6, 5, 4] and l[0].tolist() == [1, 0, 0]
+
+
+def _rand_match_case(rng, B, N, G, C, S=256):
+    cx, cy = rng.uniform(0, S, (2, N))
+    w, h = rng.uniform(4, S / 2, (2, N))
+    anchors = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).astype(F)
+    gx, gy = rng.uniform(0, S, (2, B, G))
+    gw, gh = rng.uniform(4, S / 2, (2, B, G))
+    gt = np.stack([gx - gw / 2, gy - gh / 2, gx + gw / 2, gy + gh / 2], -1).astype(F)
+    # make some GT identical to anchors (IoU 1, ties) and some rows padded
+    gt[:, 0] = anchors[:B]
+    gt[:, 1] = anchors[:B]
+    labels = rng.integers(0, C, (B, G)).astype(np.int32)
+    npad = rng.integers(0, G // 2, B)
+    for b in range(B):
+        if npad[b]:
+            gt[b, G - npad[b]:] = -1
+            labels[b, G - npad[b]:] = -1
+    return anchors, gt, labels
+
+
+def test_c_and_numpy_match_encode_agree():
+    rng = np.random.default_rng(7)
+    anchors, gt, labels = _rand_match_case(rng, 3, 700, 12, 5)
+    ref = O.anchor_targets_bbox(anchors, (256, 200), gt, labels, 5)
+    got = c_oracle.match_encode(anchors, (256, 200), gt, labels, 5, threads=2)
+    for key in ('match_idx', 'state', 'max_iou', 'labels', 'regression'):
+        np.testing.assert_array_equal(ref[key], got[key], err_msg=key)
+    np.testing.assert_array_equal(O.bbox_overlap(np.broadcast_to(anchors, (3,) + anchors.shape), gt),
+                                  c_oracle.bbox_overlap(anchors, gt))
+
+
+def test_c_and_numpy_decode_nms_agree():
+    rng = np.random.default_rng(11)
+    N, C, B = 900, 7, 2
+    anchors = O.tile_anchors(O.base_anchors(32, (1, 2, .5)), 10, 10, 8)
+    regress = np.clip(rng.normal(0, 0.5, (B, N, 4)), -2, 2).astype(F)
+    scores = rng.uniform(0, 0.25, (B, N, C)).astype(F)
+    hot = rng.integers(0, N, (B, 200))
+    for b in range(B):
+        scores[b, hot[b], rng.integers(0, C, 200)] = (np.floor((0.3 + 0.7 * rng.uniform(size=200)) * 64) / 64).astype(F)
+    ref = O.decode_and_nms(anchors, regress, scores, (80, 80), max_ret=20)
+    got = c_oracle.decode_nms(anchors, regress, scores, (80, 80), max_ret=20, threads=2)
+    for r, g, name in zip(ref, got, ('boxes', 'scores', 'labels', 'keep', 'count')):
+        np.testing.assert_array_equal(r, g, err_msg=name)
+    assert ref[4].min() > 0
