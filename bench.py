@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the box-processing hot path on N MI355X (one process per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE pass of match+encode (odbox_match_encode: IoU matching + target encoding,
+dense [B,N,5] + [B,N,C+1] outputs) over one per-GPU batch of BASELINE.json configs[1]
+(YOLOv3-shaped 416x416 grid, 10 647 anchors, 80 classes, 20 GT boxes, batch 64 per GPU), inputs
+resident in HBM.  Images are independent, so ranks hold different images and exchange nothing
+(weak scaling).  The same JSON line carries
+  roofline      the match_encode kernel against the 8 TB/s HBM peak (algorithmic bytes / HIP-event time),
+  cpu_baseline  the oracle's C restatement timed on this host's cores on a bounded sample,
+  decode_nms    the inference-side path (configs[4]: 49 104 anchors, 90 classes, 64 images per GPU,
+                + one RCCL all-gather of the detections when N > 1), reported beside it.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from object_detection_amd import _lib, anchors as A, bndbox as BB, dist as oddist, workloads  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (about 6.3 TB/s achievable)
+
+
+def yolo_grid_anchors(S=416):
+    parts = []
+    for size, stride in ((32, 8), (64, 16), (128, 32)):
+        g = A.AnchorGenerator(size, [1], stride)
+        parts.append(g((S // stride, S // stride, 3)))
+    return torch.cat(parts, 0)
+
+
+def barrier(world):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(x, world):
+    if world == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def timed(fn, steps, warmup, world):
+    """W untimed + exactly K timed calls, barrier + synchronize on both sides; returns
+    (max-over-ranks wall seconds, HIP-event seconds on the launch stream of this rank)."""
+    for _ in range(warmup):
+        fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    barrier(world)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    barrier(world)
+    wall = time.perf_counter() - t0
+    return max_over_ranks(wall, world), e0.elapsed_time(e1) * 1e-3
+
+
+def cpu_baseline_match(anchors_np, gt, lab, C, S, budget_s=6.0):
+    """The oracle's C restatement (kind "port") on this host: same cfg-2 batch, repeated until
+    about `budget_s` seconds per thread setting."""
+    from oracle import c_oracle
+    out = {}
+    B = gt.shape[0]
+    for name, threads in (('multi', min(16, os.cpu_count() or 1)), ('single', 1)):
+        c_oracle.match_encode(anchors_np, (S, S), gt[:8], lab[:8], C, threads=threads)     # warm
+        n, t0 = 0, time.perf_counter()
+        while True:
+            c_oracle.match_encode(anchors_np, (S, S), gt, lab, C, threads=threads)
+            n += B
+            el = time.perf_counter() - t0
+            if el > budget_s:
+                break
+        out[name] = (n / el, threads, n)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--nms-steps', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-nms', action='store_true')
+    args = ap.parse_args()
+
+    rank, world = oddist.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+    lib = _lib.load()
+    dev = _lib.require_gpu()
+    stream = _lib.stream_ptr()
+
+    # ---------------- match + encode, configs[1] ------------------------------------------
+    cfg = workloads.CONFIGS[2]
+    S, B, G, C = cfg['S'], cfg['B'], cfg['G'], cfg['C']
+    anchors = yolo_grid_anchors(S)
+    N = anchors.shape[0]
+    assert N == workloads.num_anchors(2)
+    gt_np, lab_np = workloads.match_inputs(2, seed=1002 + 7919 * rank)
+    gt = torch.as_tensor(gt_np).to(dev)
+    lab = torch.as_tensor(lab_np).to(dev)
+    reg = torch.empty((B, N, 5), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, N, C + 1), dtype=torch.float32, device=dev)
+
+    def step():
+        rc = lib.odbox_match_encode(anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C,
+                                    float(S), float(S), 0.4, 0.5, reg.data_ptr(), labels.data_ptr(),
+                                    None, None, None, stream)
+        if rc:
+            _lib.check(rc, 'odbox_match_encode')
+
+    wall, ev = timed(step, args.steps, args.warmup, world)
+    img_s = world * B * args.steps / wall
+    bytes_per_launch = B * workloads.match_bytes_per_image(N, G, C)
+    kernel_s = ev / args.steps
+    achieved = bytes_per_launch / kernel_s / 1e9
+
+    result = {
+        'metric': 'images/sec match+encode (IoU matching + target encoding)',
+        'value': round(img_s, 1),
+        'unit': 'images/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': round(wall / args.steps * 1e3, 5),
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': 'configs[1]: YOLOv3-shaped 416x416 grid, 3 strides x 3 anchors = %d anchors, '
+                               '%d classes, %d GT boxes/img, batch %d per GPU, dense [B,N,5]+[B,N,C+1] outputs'
+                               % (N, C, G, B),
+                   'global_batch': world * B, 'anchors': N, 'classes': C, 'gt_per_image': G,
+                   'parallelism': 'images sharded over %d GPU(s), no collective' % world},
+        'roofline': {'bound': 'hbm', 'kernel': 'match_encode_kernel',
+                     'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': round(achieved / HBM_PEAK_GBS, 4),
+                     'bytes_per_launch': bytes_per_launch, 'us_per_launch': round(kernel_s * 1e6, 3),
+                     'traffic': load_traffic('match_encode_kernel')},
+    }
+
+    # ---------------- decode + NMS, configs[4] per-GPU share -------------------------------
+    if not args.no_nms:
+        S5, B5, C5 = 512, 64, 90
+        anchors5 = A.generate_anchors(A.AnchorsConfig(), S5)
+        N5 = anchors5.shape[0]
+        reg5_np, sc5_np = workloads.nms_inputs(N5, C=C5, batch=B5, seed=1005 + 7919 * rank,
+                                               p3p4_anchors=9 * (64 * 64 + 32 * 32))
+        reg5 = torch.as_tensor(reg5_np).to(dev)
+        sc5 = torch.as_tensor(sc5_np).to(dev)
+        del reg5_np, sc5_np
+        out = {}
+
+        def nms_step():
+            b, s, l = BB.decode_and_nms(anchors5, reg5, sc5, (S5, S5))
+            out['det'] = oddist.gather_detections(b, s, l, batch=None)
+
+        wall5, ev5 = timed(nms_step, args.nms_steps, 3, world)
+        bytes5 = B5 * workloads.nms_bytes_per_image(N5, C5)
+        ach5 = bytes5 / (ev5 / args.nms_steps) / 1e9
+        result['decode_nms'] = {
+            'metric': 'images/sec decode+clip+per-class NMS+top-k' + (' + RCCL all-gather' if world > 1 else ''),
+            'value': round(world * B5 * args.nms_steps / wall5, 1), 'unit': 'images/s',
+            'ms_per_step': round(wall5 / args.nms_steps * 1e3, 4), 'steps': args.nms_steps,
+            'config': {'workload': 'configs[4] per-GPU share: %d anchors, %d classes, batch %d per GPU, '
+                                   'score 0.3, IoU 0.45, max_ret 100, ~4500 candidates/img' % (N5, C5, B5)},
+            'roofline': {'bound': 'hbm', 'kernel': 'whole decode+NMS pipeline (score_scan dominates)',
+                         'achieved': round(ach5, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(ach5 / HBM_PEAK_GBS, 4), 'bytes_per_launch': bytes5,
+                         'traffic': load_traffic('score_scan_kernel')},
+            'detections_per_image_mean': float((out['det'][1] > 0).sum().item()) / (world * B5),
+        }
+
+    # ---------------- CPU baseline (rank 0, N = 1 only) ------------------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cb = cpu_baseline_match(anchors.cpu().numpy(), gt_np, lab_np, C, S)
+        result['cpu_baseline'] = {
+            'value': round(cb['multi'][0], 1), 'unit': 'images/s', 'cores': cb['multi'][1], 'kind': 'port',
+            'sample': 'oracle/odbox_oracle.c (CPU restatement with TF semantics, not TensorFlow) on the same '
+                      'cfg-2 batch of %d images, repeated to %d images, OpenMP over images' % (B, cb['multi'][2]),
+            'value_1core': round(cb['single'][0], 1),
+            'host_cpus': os.cpu_count(),
+        }
+    elif rank == 0:
+        result['cpu_baseline'] = None
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def load_traffic(kernel):
+    """HBM bytes per launch from the PMC passes (profiles/pmc_traffic.json, written from the
+    rocprofv3 --pmc runs of profiles/README.md); null until collected."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel, {}).get('hbm_bytes_per_launch')
+    except (OSError, ValueError):
+        return None
+
+
+if __name__ == '__main__':
+    main()

@@ -731,8 +731,9 @@ const char *odbox_last_error(void) { return g_err; }
 
 int odbox_anchor_tile(const float *base, int A, int fh, int fw, float stride, float *out, void *stream)
 {
-    if (!base || !out) return fail(ODBOX_EINVAL, "odbox_anchor_tile: NULL pointer");
     if (A < 1 || fh < 0 || fw < 0) return fail(ODBOX_EINVAL, "odbox_anchor_tile: bad shape A=%d fh=%d fw=%d", A, fh, fw);
+    if (fh == 0 || fw == 0) return 0;
+    if (!base || !out) return fail(ODBOX_EINVAL, "odbox_anchor_tile: NULL pointer");
     if (!aligned16(base) || !aligned16(out)) return fail(ODBOX_EINVAL, "odbox_anchor_tile: pointers must be 16-byte aligned");
     const uint64_t total = (uint64_t)fh * fw * A;
     if (total == 0) return 0;
@@ -747,10 +748,12 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
                        float *out_regression, float *out_labels, int32_t *out_match_idx, int8_t *out_state,
                        float *out_max_iou, void *stream)
 {
+    if (B < 0 || N < 0 || G < 1 || C < 1 || C > ODBOX_MAX_CLASSES)
+        return fail(ODBOX_EINVAL, "odbox_match_encode: bad shape B=%d N=%d G=%d C=%d (need G>=1, 1<=C<=%d)", B, N, G, C,
+                    ODBOX_MAX_CLASSES);
+    if (B == 0 || N == 0) return 0;
     if (!anchors || !gt_boxes) return fail(ODBOX_EINVAL, "odbox_match_encode: NULL input");
     if (out_labels && !gt_labels) return fail(ODBOX_EINVAL, "odbox_match_encode: out_labels needs gt_labels");
-    if (B < 0 || N < 0 || G < 1 || C < 1 || C > ODBOX_MAX_CLASSES)
-        return fail(ODBOX_EINVAL, "odbox_match_encode: bad shape B=%d N=%d G=%d C=%d", B, N, G, C);
     if (!aligned16(anchors) || !aligned16(gt_boxes))
         return fail(ODBOX_EINVAL, "odbox_match_encode: anchors / gt_boxes must be 16-byte aligned");
     if (B == 0 || N == 0) return 0;
@@ -769,8 +772,9 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
 int odbox_bbox_overlap(const float *anchors, const float *gt_boxes, int B, int N, int G, int anchors_batched,
                        float *out_iou, void *stream)
 {
-    if (!anchors || !gt_boxes || !out_iou) return fail(ODBOX_EINVAL, "odbox_bbox_overlap: NULL pointer");
     if (B < 0 || N < 0 || G < 0) return fail(ODBOX_EINVAL, "odbox_bbox_overlap: bad shape");
+    if ((size_t)B * N * G == 0) return 0;
+    if (!anchors || !gt_boxes || !out_iou) return fail(ODBOX_EINVAL, "odbox_bbox_overlap: NULL pointer");
     if (!aligned16(anchors) || !aligned16(gt_boxes))
         return fail(ODBOX_EINVAL, "odbox_bbox_overlap: inputs must be 16-byte aligned");
     const size_t total = (size_t)B * N * G;
@@ -785,6 +789,8 @@ int odbox_bbox_overlap(const float *anchors, const float *gt_boxes, int B, int N
 static int elementwise_check(const char *name, const void *a, const void *b, const void *c, size_t total,
                              size_t &blocks)
 {
+    blocks = 0;
+    if (total == 0) return 0;
     if (!a || !b || !c) return fail(ODBOX_EINVAL, "%s: NULL pointer", name);
     if (!aligned16(a) || !aligned16(b) || !aligned16(c)) return fail(ODBOX_EINVAL, "%s: pointers must be 16-byte aligned", name);
     blocks = (total + 255) / 256;

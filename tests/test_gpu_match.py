@@ -1,0 +1,180 @@
+"""GPU parity of the training-side path (anchor tiling, IoU matching, target encoding) against
+the CPU oracle, through the C-ABI (ctypes) as bound by object_detection_amd.anchors.
+Bars (BASELINE.json north_star): match indices, states and one-hot labels bit-exact; encoded
+offsets within 1e-5 relative (they are in fact compared bit-exact first and only fall back to
+the tolerance if the division differs)."""
+import numpy as np
+import pytest
+import torch
+
+from object_detection_amd import anchors as A
+from object_detection_amd import bndbox as BB
+from object_detection_amd import config, workloads
+from oracle import c_oracle
+from oracle import odbox_oracle as O
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+RTOL = 1e-5
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def check_targets(anchors_np, hw, gt, lab, C, neg=0.4, pos=0.5):
+    got = A.match_encode(anchors_np, hw, gt, lab, C, neg, pos, dense=True, compact=True)
+    ref = c_oracle.match_encode(anchors_np, hw, gt, lab, C, neg, pos, threads=8)
+    np.testing.assert_array_equal(cpu(got['match_idx']), ref['match_idx'])
+    np.testing.assert_array_equal(cpu(got['state']), ref['state'])
+    np.testing.assert_array_equal(cpu(got['max_iou']), ref['max_iou'])
+    np.testing.assert_array_equal(cpu(got['labels']), ref['labels'])
+    reg = cpu(got['regression'])
+    np.testing.assert_array_equal(reg[..., 4], ref['regression'][..., 4])
+    with np.errstate(invalid='ignore'):
+        np.testing.assert_allclose(reg, ref['regression'], rtol=RTOL, atol=0, equal_nan=True)
+    return got, ref
+
+
+@pytest.mark.parametrize('S', [512, 1024, 416 + 96])
+def test_generate_anchors_bit_exact(S):
+    got = cpu(A.generate_anchors(config.AnchorsConfig(), S))
+    np.testing.assert_array_equal(got, O.generate_anchors(S))
+
+
+def test_anchor_generator_api():
+    g = A.AnchorGenerator(32, [1], 8)
+    assert len(g) == 3 and g.anchors.shape == (3, 4)
+    np.testing.assert_array_equal(g.anchors.numpy(), O.base_anchors(32, [1]))
+    t = cpu(g((5, 7, 3)))
+    np.testing.assert_array_equal(t, O.tile_anchors(O.base_anchors(32, [1]), 5, 7, 8))
+    assert cpu(g.tile_anchors_over_feature_map((0, 4))).shape == (0, 4)
+
+
+def test_known_answers_on_gpu():
+    anchors = F([[0, 0, 10, 10]])
+    for gt_row, state in (([0, 0, 10, 5], 1), ([0, 0, 10, 4], 0), ([0, 0, 10, 4.5], -1)):
+        reg, lab = A.anchor_targets_bbox(anchors, (1, 512, 512, 3), F([[gt_row]]), np.int32([[2]]), 3)
+        assert cpu(lab)[0, 0, 3] == state and cpu(reg)[0, 0, 4] == state
+        assert cpu(lab)[0, 0, :3].tolist() == ([0, 0, 1] if state == 1 else [0, 0, 0])
+    reg, lab = A.anchor_targets_bbox(F([[0, 0, 10, 20]]), (1, 64, 64, 3), F([[[1, 2, 11, 18]]]), np.int32([[0]]), 1)
+    np.testing.assert_allclose(cpu(reg)[0, 0, :4], [0.5, 0.5, 0.5, -0.5], rtol=1e-6)
+    # out-of-image centre -> ignored even at IoU 1
+    reg, lab = A.anchor_targets_bbox(F([[500, 10, 530, 40]]), (1, 512, 512, 3), F([[[500, 10, 530, 40]]]),
+                                     np.int32([[0]]), 1)
+    assert cpu(lab)[0, 0].tolist() == [0, -1]
+
+
+@pytest.mark.parametrize('B,N,G,C', [(1, 1, 1, 1), (2, 255, 3, 1), (3, 257, 7, 2), (2, 1000, 20, 80),
+                                     (1, 513, 64, 3), (2, 300, 600, 5), (1, 4099, 1030, 90)])
+def test_random_shapes_bit_exact(B, N, G, C):
+    rng = np.random.default_rng(B * 1000 + N + G + C)
+    S = 256
+    cx, cy = rng.uniform(0, S, (2, N))
+    w, h = rng.uniform(4, S / 2, (2, N))
+    anchors = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).astype(F)
+    gx, gy = rng.uniform(0, S, (2, B, G))
+    gw, gh = rng.uniform(4, S / 2, (2, B, G))
+    gt = np.stack([gx - gw / 2, gy - gh / 2, gx + gw / 2, gy + gh / 2], -1).astype(F)
+    k = min(N, G, 4)
+    gt[:, :k] = anchors[:k]                      # exact matches
+    if G > 2:
+        gt[:, 2] = gt[:, 0]                      # duplicate row -> argmax tie
+    lab = rng.integers(0, C, (B, G)).astype(np.int32)
+    if G > 4:
+        gt[:, -2:] = -1
+        lab[:, -2:] = -1
+    check_targets(anchors, (S, S - 40), gt, lab, C)
+
+
+def test_all_padded_and_out_of_range_labels():
+    anchors = O.tile_anchors(O.base_anchors(32, (1, 2, .5)), 6, 6, 8)
+    gt = np.full((2, 5, 4), -1, F)
+    lab = np.full((2, 5), -1, np.int32)
+    gt[1, 0] = anchors[10]
+    lab[1, 0] = 7                                # >= num_classes: tf.one_hot gives a zero row
+    got, ref = check_targets(anchors, (48, 48), gt, lab, 4)
+    assert (cpu(got['state'])[0] == -1).all() and (cpu(got['match_idx'])[0] == 0).all()
+    assert cpu(got['labels'])[1, 10].tolist() == [0, 0, 0, 0, 1]
+
+
+def test_padded_64_rows_20_valid():
+    S, C = 512, 80
+    anchors = O.generate_anchors(S)
+    gt, lab = workloads.match_inputs(1, batch=2, pad_to=64)
+    assert gt.shape == (2, 64, 4)
+    check_targets(anchors, (S, S), gt, lab, C)
+
+
+def test_cfg1_full_size():
+    anchors = O.generate_anchors(512)
+    gt, lab = workloads.match_inputs(1)
+    got, ref = check_targets(anchors, (512, 512), gt, lab, 80)
+    assert (ref['state'] == 1).sum() > 0
+
+
+def test_cfg2_full_size_yolo_grid():
+    anchors = O.yolo_shaped_anchors(416)
+    gt, lab = workloads.match_inputs(2)
+    check_targets(anchors, (416, 416), gt, lab, 80)
+
+
+def test_cfg4_dense_crowd_slice():
+    anchors = O.generate_anchors(512)
+    gt, lab = workloads.match_inputs(4, batch=4)
+    assert gt.shape == (4, 500, 4)
+    check_targets(anchors, (512, 512), gt, lab, 1)
+
+
+def test_cfg3_large_properties():
+    """cfg 3 at full per-GPU size (B=32, N=196416): compact outputs vs the oracle, dense outputs
+    through size-independent properties (row sums / state column / one-hot position)."""
+    anchors = O.generate_anchors(1024)
+    gt, lab = workloads.match_inputs(3, batch=32)
+    got = A.match_encode(anchors, (1024, 1024), gt, lab, 80, dense=True, compact=True)
+    ref = c_oracle.match_encode(anchors, (1024, 1024), gt, lab, 80, threads=8, dense=False)
+    midx, state = got['match_idx'], got['state']
+    np.testing.assert_array_equal(cpu(midx), ref['match_idx'])
+    np.testing.assert_array_equal(cpu(state), ref['state'])
+    labels, reg = got['labels'], got['regression']
+    st = state.to(torch.float32)
+    assert torch.equal(labels[..., 80], st) and torch.equal(reg[..., 4], st)
+    assert torch.equal(labels[..., :80].sum(-1), (state == 1).to(torch.float32))
+    want_cls = torch.gather(torch.as_tensor(lab).cuda().long(), 1, midx.long())
+    pos = state == 1
+    assert torch.equal(labels[..., :80].argmax(-1)[pos], want_cls[pos])
+
+
+def test_compute_gt_annotations_and_overlap_and_transform():
+    rng = np.random.default_rng(5)
+    anchors = O.tile_anchors(O.base_anchors(32, (1, 2, .5)), 9, 9, 8)
+    gts = [workloads.gt_boxes(rng, 72, 6, 3, pad_to=8) for _ in range(3)]
+    gt = np.stack([g[0] for g in gts])
+    pos, ign, idx = A.compute_gt_annotations(anchors, gt)
+    rpos, rign, ridx, _ = O.compute_gt_annotations(anchors, gt)
+    np.testing.assert_array_equal(cpu(pos), rpos)
+    np.testing.assert_array_equal(cpu(ign), rign)
+    np.testing.assert_array_equal(cpu(idx), ridx)
+    assert idx.dtype == torch.int32 and pos.dtype == torch.bool
+    iou = BB.bbox_overlap(np.broadcast_to(anchors, (3,) + anchors.shape).copy(), gt)
+    np.testing.assert_array_equal(cpu(iou), O.bbox_overlap(np.broadcast_to(anchors, (3,) + anchors.shape), gt))
+    np.testing.assert_array_equal(cpu(BB.bbox_overlap(anchors, gt)), cpu(iou))
+    chosen = np.take_along_axis(gt, ridx[:, 1].reshape(3, -1, 1), axis=1)
+    t = A.bbox_transform(anchors, chosen)
+    np.testing.assert_allclose(cpu(t), O.bbox_transform(anchors[None], chosen), rtol=RTOL)
+
+
+def test_fp16_gt_is_cast_like_the_reference():
+    anchors = O.tile_anchors(O.base_anchors(32, (1, 2, .5)), 4, 4, 8)
+    gt16 = torch.tensor([[[3.5, 2.25, 30.0, 28.0]]], dtype=torch.float16)
+    reg, lab = A.anchor_targets_bbox(anchors, (1, 32, 32, 3), gt16, torch.tensor([[1]]), 2)
+    ref = c_oracle.match_encode(anchors, (32, 32), gt16.float().numpy(), np.int32([[1]]), 2)
+    np.testing.assert_array_equal(cpu(lab), ref['labels'])
+
+
+def test_bad_arguments_raise():
+    from object_detection_amd._lib import OdboxError
+    with pytest.raises(ValueError):
+        A.anchor_targets_bbox(np.zeros((4, 3), F), (1, 8, 8, 3), np.zeros((1, 2, 4), F), np.zeros((1, 2), np.int32), 2)
+    with pytest.raises(OdboxError):
+        A.match_encode(np.zeros((4, 4), F), (8, 8), np.zeros((1, 2, 4), F), np.zeros((1, 2), np.int32), 5000)

@@ -1,0 +1,167 @@
+"""GPU parity of the inference-side path (decode, clip, per-class NMS, top-k) against the CPU
+oracle through the C-ABI.  Bars: keep-lists (anchor ids), labels and scores bit-exact; decoded
+boxes within 1e-5 relative."""
+import numpy as np
+import pytest
+import torch
+
+from object_detection_amd import bndbox as BB
+from object_detection_amd import workloads
+from oracle import c_oracle
+from oracle import odbox_oracle as O
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+RTOL = 1e-5
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def check(got, want):
+    got = [cpu(t) for t in got]
+    np.testing.assert_array_equal(got[4], want[4], err_msg='count')
+    np.testing.assert_array_equal(got[3], want[3], err_msg='keep anchors')
+    np.testing.assert_array_equal(got[2], want[2], err_msg='labels')
+    np.testing.assert_array_equal(got[1], want[1], err_msg='scores')
+    np.testing.assert_allclose(got[0], want[0], rtol=RTOL, atol=0, err_msg='boxes')
+
+
+def _nms1(boxes, scores, **kw):
+    out = BB.nms(F(boxes)[None], F(scores)[None], return_keep=True, **kw)
+    return [cpu(t) for t in out]
+
+
+def test_nms_known_answers_on_gpu():
+    box = [0, 0, 10, 10]
+    b, s, l, k, n = _nms1([box, box], [[0.9, 0.1], [0.9, 0.1]])
+    assert n[0] == 1 and k[0, 0] == 0 and l[0, 0] == 0 and s[0, 0] == F(0.9)
+    assert (s[0, 1:] == 0).all() and (l[0, 1:] == 0).all() and (b[0, 1:] == 0).all() and (k[0, 1:] == -1).all()
+    b, s, l, k, n = _nms1([box, box], [[0.9, 0.1], [0.1, 0.9]])
+    assert n[0] == 2 and l[0, :2].tolist() == [0, 1] and k[0, :2].tolist() == [0, 1]
+    b, s, l, k, n = _nms1([box], [[0.3, 0.1]])
+    assert n[0] == 0 and (s == 0).all()
+    b, s, l, k, n = _nms1([[0, 0, 10, 10], [0, 0, 10, 5]], [[0.9], [0.8]], iou_threshold=0.5)
+    assert n[0] == 2
+    b, s, l, k, n = _nms1([[0, 0, 10, 10], [0, 0, 10, 5]], [[0.9], [0.8]], iou_threshold=0.49)
+    assert n[0] == 1
+    b, s, l, k, n = _nms1([[5, 5, 5, 9], [5, 5, 5, 9]], [[0.9], [0.8]])
+    assert n[0] == 2
+    b, s, l, k, n = _nms1([box], [[0.1, 0.2]])
+    assert n[0] == 0 and (b == 0).all() and (s == 0).all() and (l == 0).all()
+    boxes = [[20 * i, 0, 20 * i + 10, 10] for i in range(8)]
+    scores = [[0.50 + 0.01 * i, 0] for i in range(6)] + [[0, 0.95], [0, 0.40]]
+    b, s, l, k, n = _nms1(boxes, scores, max_ret=3)
+    assert n[0] == 3 and k[0].tolist() == [6, 5, 4] and l[0].tolist() == [1, 0, 0]
+
+
+def _case(rng, B, N, C, hot, quant=64, S=160):
+    side = int(np.ceil(np.sqrt(N / 9)))
+    anchors = O.tile_anchors(O.base_anchors(32, (1, 2, .5)), side, side, 8)[:N]
+    regress = np.clip(rng.normal(0, 0.5, (B, N, 4)), -2, 2).astype(F)
+    scores = rng.uniform(0, 0.25, (B, N, C)).astype(F)
+    for b in range(B):
+        idx = rng.integers(0, N, hot)
+        cls = rng.integers(0, C, hot)
+        scores[b, idx, cls] = (np.floor((0.3 + 0.7 * rng.uniform(size=hot)) * quant) / quant).astype(F)
+    return anchors, regress, scores
+
+
+@pytest.mark.parametrize('B,N,C,hot,max_ret', [
+    (1, 64, 1, 10, 100), (2, 900, 7, 200, 20), (3, 1000, 90, 400, 100), (2, 2500, 80, 2000, 100),
+    (1, 777, 3, 700, 5), (2, 4000, 1, 3000, 100), (1, 3001, 33, 500, 300)])
+def test_decode_nms_random(B, N, C, hot, max_ret):
+    rng = np.random.default_rng(N + C + hot)
+    anchors, regress, scores = _case(rng, B, N, C, hot)
+    S = 160
+    got = BB.decode_and_nms(anchors, regress, scores, (S, S), max_ret=max_ret, return_keep=True)
+    want = c_oracle.decode_nms(anchors, regress, scores, (S, S), max_ret=max_ret, threads=4)
+    check(got, want)
+
+
+def test_plain_nms_entry_and_elementwise_ops():
+    rng = np.random.default_rng(42)
+    anchors, regress, scores = _case(rng, 2, 1200, 12, 300)
+    dec = BB.regress_bndboxes(np.broadcast_to(anchors, regress.shape).copy(), regress)
+    np.testing.assert_allclose(cpu(dec), O.regress_bndboxes(anchors[None], regress), rtol=RTOL)
+    np.testing.assert_array_equal(cpu(BB.regress_bndboxes(anchors, regress)), cpu(dec))
+    clipped = BB.clip_boxes(dec, (160, 120))
+    np.testing.assert_array_equal(cpu(clipped), O.clip_boxes(cpu(dec), (160, 120)))
+    got = BB.nms(clipped, scores, return_keep=True)
+    want = c_oracle.decode_nms(None, cpu(clipped), scores, (160, 120), do_clip=False)
+    check(got, want)
+    b3 = BB.nms(clipped, scores)
+    assert len(b3) == 3 and b3[2].dtype == torch.int32 and tuple(b3[0].shape) == (2, 100, 4)
+    flat = cpu(clipped)[0]
+    np.testing.assert_array_equal(cpu(BB.scale_boxes(flat, (160, 120), (512, 384))), O.scale_boxes(flat, (160, 120), (512, 384)))
+    np.testing.assert_array_equal(cpu(BB.normalize_bndboxes(flat, (160, 120))), O.normalize_bndboxes(flat, (160, 120)))
+
+
+def test_numpy_oracle_agrees_on_small_case():
+    rng = np.random.default_rng(9)
+    anchors, regress, scores = _case(rng, 1, 500, 5, 150)
+    got = BB.decode_and_nms(anchors, regress, scores, (160, 160), max_ret=30, return_keep=True)
+    check(got, O.decode_and_nms(anchors, regress, scores, (160, 160), max_ret=30))
+
+
+def test_all_scores_equal_ties_resolved_by_anchor_order():
+    N, C = 300, 4
+    anchors = O.tile_anchors(O.base_anchors(32, [1]), 10, 10, 8)
+    regress = np.zeros((1, N, 4), F)
+    scores = np.zeros((1, N, C), F)
+    scores[0, :, 2] = 0.5
+    scores[0, ::3, 1] = 0.5                     # argmax tie inside a row -> lower class
+    got = BB.decode_and_nms(anchors, regress, scores, (80, 80), return_keep=True)
+    want = c_oracle.decode_nms(anchors, regress, scores, (80, 80))
+    check(got, want)
+
+
+def test_large_candidate_count_takes_global_sort_path():
+    # more than 16384 candidates in one image: the sort runs in global memory
+    rng = np.random.default_rng(1)
+    N, C = 20000, 6
+    anchors = O.tile_anchors(O.base_anchors(16, (1, 2, .5)), 48, 48, 4)[:N]
+    regress = np.clip(rng.normal(0, 0.3, (1, N, 4)), -1, 1).astype(F)
+    scores = (np.floor(rng.uniform(0.31, 1.0, (1, N, C)) * 4096) / 4096).astype(F)
+    got = BB.decode_and_nms(anchors, regress, scores, (192, 192), max_ret=50, return_keep=True)
+    want = c_oracle.decode_nms(anchors, regress, scores, (192, 192), max_ret=50, threads=4)
+    check(got, want)
+
+
+def test_cfg5_slice_full_anchor_set():
+    anchors = O.generate_anchors(512)
+    N = anchors.shape[0]
+    regress, scores = workloads.nms_inputs(N, C=90, batch=4, distinct=4, p3p4_anchors=9 * (64 * 64 + 32 * 32))
+    got = BB.decode_and_nms(anchors, regress, scores, (512, 512), return_keep=True)
+    want = c_oracle.decode_nms(anchors, regress, scores, (512, 512), threads=4)
+    check(got, want)
+    assert want[4].min() > 10
+
+
+def test_pre_nms_topk_extension():
+    rng = np.random.default_rng(3)
+    anchors, regress, scores = _case(rng, 2, 2000, 9, 1500, quant=1 << 20)
+    got = BB.decode_and_nms(anchors, regress, scores, (160, 160), pre_nms_topk=300, return_keep=True)
+    # oracle of the extension: zero the scores of everything outside the per-image top 300
+    best = scores.max(-1)
+    masked = scores.copy()
+    for b in range(2):
+        order = sorted(range(2000), key=lambda i: (-float(best[b, i]), i))
+        masked[b, order[300:]] = 0
+    want = c_oracle.decode_nms(anchors, regress, masked, (160, 160))
+    check(got, want)
+    # non-binding bound == unbounded
+    a = BB.decode_and_nms(anchors, regress, scores, (160, 160), pre_nms_topk=5000, return_keep=True)
+    check(a, c_oracle.decode_nms(anchors, regress, scores, (160, 160)))
+
+
+def test_idempotent_and_workspace_reuse():
+    rng = np.random.default_rng(8)
+    anchors, regress, scores = _case(rng, 2, 1500, 10, 600)
+    first = BB.decode_and_nms(anchors, regress, scores, (160, 160), return_keep=True)
+    small = BB.decode_and_nms(anchors[:100], regress[:, :100], scores[:, :100], (160, 160), return_keep=True)
+    again = BB.decode_and_nms(anchors, regress, scores, (160, 160), return_keep=True)
+    for x, y in zip(first, again):
+        assert torch.equal(x, y)
+    check(small, c_oracle.decode_nms(anchors[:100], regress[:, :100], scores[:, :100], (160, 160)))
