@@ -12,6 +12,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "odbox.h"
 
@@ -50,6 +51,9 @@ inline int launch_status(const char *what)
 // small device helpers
 // ------------------------------------------------------------------------------------------
 constexpr int WAVE = 64;
+// ints between per-image atomic counters: returning atomics on one cache line serialise in L2
+// (measured: 64 counters packed in 256 B cap a kernel at ~240 atomics/us chip-wide)
+constexpr uint32_t CNT_STRIDE = 64;
 
 // Blocks are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2), so give each
 // XCD a contiguous run of tiles: neighbouring output tiles then meet in one L2.  Bijective for
@@ -377,117 +381,271 @@ __global__ __launch_bounds__(256) void transform_kernel(const float4 *__restrict
 // ------------------------------------------------------------------------------------------
 // decode + NMS, kernel 1: stream the [B,N,C] scores once (the HBM-bound kernel).
 //
-// One wave (= one 64-thread block) owns a tile of 64*RPL consecutive rows = one contiguous
-// run of bytes.  The tile goes HBM -> LDS by LDS-DMA (global_load_lds, 16 B per lane when the
-// run is 16-byte aligned, 4 B otherwise; no VGPR staging), then lane l reduces rows l, l+64..
-// out of LDS.  Row r starts its scan at column (r * skew) mod C so that the 32 lanes of a
-// ds_read_b32 group hit 32 different banks for every C (skew makes the lane stride odd); the
-// rotated scan keeps tf.argmax's first-max rule through an explicit (value, column) compare.
-// Rows with max score > threshold append one 64-bit key to the image's candidate list
-// (one atomic per wave).  bndbox.py:153-154 (argmax / reduce_max), :205 (score filter).
+// Persistent single-wave workgroups, each with two LDS buffers.  A tile = R consecutive rows
+// of the score matrix = one contiguous run of R*C floats.  Tile i+1 goes HBM -> LDS by LDS-DMA
+// (global_load_lds, 16 B per lane when the run is 16-byte aligned, else 4 B; no VGPR staging)
+// while tile i is reduced out of the other buffer.  In the reduce, LPR adjacent lanes share a
+// row and read V*LPR consecutive floats per instruction (ds_read_b32/b64/b128 by C's
+// divisibility), so LDS reads are bank-conflict free for every C without padding (the DMA image
+// must stay linear); the row maximum is finished with xor-shuffles inside the lane group.
+// Only rows with max > threshold (rare) take the second pass that finds tf.argmax's FIRST
+// maximal column, and append one 64-bit key to the image's candidate list (one atomic per
+// wave-step).  bndbox.py:153-154 (argmax / reduce_max), :205 (score filter).
 // ------------------------------------------------------------------------------------------
-template <int VEC>
-__device__ __forceinline__ void dma_tile(const float *src, float *lds, uint32_t nfloat, uint32_t lane)
+struct ScanGeom {
+    int V;             // floats per LDS read: 4 if C%4==0, 2 if C%2==0, else 1
+    int lpr_log2;      // log2(lanes per row)
+    int K;             // reads per lane per row = ceil(C / (V * LPR))
+    int kfull;         // leading reads that are in range for every lane = C / (V * LPR)
+    int steps;         // wave-steps per tile; rows per tile R = steps * (64 >> lpr_log2)
+    uint32_t buf_floats;   // floats per LDS buffer (multiple of 4)
+    uint32_t tpi_magic;    // floor(2^32 / tiles_per_image) for the tile -> image division
+};
+
+// LDS-DMA issued through inline asm on purpose: with the builtin, hipcc treats every later
+// ds_read as dependent on every outstanding DMA and puts s_waitcnt vmcnt(0) in front of it,
+// which would serialise the prefetch of tile i+1 with the reduce of tile i.  Here the waits are
+// ours: one s_waitcnt vmcnt(0) before a buffer is read.  M0 = wave-uniform LDS byte address;
+// lane l lands at M0 + l * size.  (M0 is a reserved register; nothing else in these kernels
+// uses it.  s_nop covers the SALU-writes-M0 -> LDS-DMA hazard.)
+__device__ __forceinline__ void dma16(const float *g, uint32_t lds_byte)
 {
-    using gptr = const __attribute__((address_space(1))) void *;
-    using lptr = __attribute__((address_space(3))) void *;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte), "v"(g) : "memory");
+}
+__device__ __forceinline__ void dma4(const float *g, uint32_t lds_byte)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_byte), "v"(g) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_address(const void *p)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+
+// contiguous run of nfloat floats: HBM -> LDS image at byte address `lds`, linear
+template <int VEC>
+__device__ __forceinline__ void dma_tile(const float *src, uint32_t lds, uint32_t nfloat, uint32_t lane)
+{
     if constexpr (VEC == 4) {
         const uint32_t nvec = nfloat >> 2;
         uint32_t i = 0;
-        for (; i + WAVE <= nvec; i += WAVE)
-            __builtin_amdgcn_global_load_lds((gptr)(src + (size_t)(i + lane) * 4), (lptr)(lds + i * 4), 16, 0, 0);
-        if (i < nvec) {   // last partial 16-byte row of lanes, then the <4 float tail
-            if (i + lane < nvec)
-                __builtin_amdgcn_global_load_lds((gptr)(src + (size_t)(i + lane) * 4), (lptr)(lds + i * 4), 16, 0, 0);
-        }
+        for (; i + WAVE <= nvec; i += WAVE) dma16(src + (size_t)(i + lane) * 4, lds + i * 16);
+        if (i + lane < nvec) dma16(src + (size_t)(i + lane) * 4, lds + i * 16);
         const uint32_t done = nvec << 2;
-        if (done + lane < nfloat)
-            __builtin_amdgcn_global_load_lds((gptr)(src + done + lane), (lptr)(lds + done), 4, 0, 0);
+        if (done + lane < nfloat) dma4(src + done + lane, lds + done * 4);
     } else {
         uint32_t i = 0;
-        for (; i + WAVE <= nfloat; i += WAVE)
-            __builtin_amdgcn_global_load_lds((gptr)(src + i + lane), (lptr)(lds + i), 4, 0, 0);
-        if (i + lane < nfloat)
-            __builtin_amdgcn_global_load_lds((gptr)(src + i + lane), (lptr)(lds + i), 4, 0, 0);
+        for (; i + WAVE <= nfloat; i += WAVE) dma4(src + i + lane, lds + i * 4);
+        if (i + lane < nfloat) dma4(src + i + lane, lds + i * 4);
     }
 }
 
+// all-reduce inside aligned groups of 2^lpr_log2 lanes.  Up to 16 lanes it is pure DPP (quad
+// permutes, row_half_mirror, row_mirror): VALU-rate, no trip through the LDS crossbar.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+template <int LL>
+__device__ __forceinline__ float group_max(float m)
+{
+    if constexpr (LL >= 1) m = fmaxf(m, __int_as_float(dpp_i<0xB1>(__float_as_int(m))));    // quad_perm [1,0,3,2]
+    if constexpr (LL >= 2) m = fmaxf(m, __int_as_float(dpp_i<0x4E>(__float_as_int(m))));    // quad_perm [2,3,0,1]
+    if constexpr (LL >= 3) m = fmaxf(m, __int_as_float(dpp_i<0x141>(__float_as_int(m))));   // row_half_mirror
+    if constexpr (LL >= 4) m = fmaxf(m, __int_as_float(dpp_i<0x140>(__float_as_int(m))));   // row_mirror
+    if constexpr (LL >= 5) m = fmaxf(m, __shfl_xor(m, 16));
+    if constexpr (LL >= 6) m = fmaxf(m, __shfl_xor(m, 32));
+    return m;
+}
+template <int LL>
+__device__ __forceinline__ uint32_t group_min(uint32_t m)
+{
+    if constexpr (LL >= 1) m = min(m, (uint32_t)dpp_i<0xB1>((int)m));
+    if constexpr (LL >= 2) m = min(m, (uint32_t)dpp_i<0x4E>((int)m));
+    if constexpr (LL >= 3) m = min(m, (uint32_t)dpp_i<0x141>((int)m));
+    if constexpr (LL >= 4) m = min(m, (uint32_t)dpp_i<0x140>((int)m));
+    if constexpr (LL >= 5) m = min(m, (uint32_t)__shfl_xor((int)m, 16));
+    if constexpr (LL >= 6) m = min(m, (uint32_t)__shfl_xor((int)m, 32));
+    return m;
+}
+
+template <int V>
+struct VecLoad;
+template <>
+struct VecLoad<1> {
+    static __device__ __forceinline__ void load(const float *p, float (&v)[1]) { v[0] = *p; }
+};
+template <>
+struct VecLoad<2> {
+    static __device__ __forceinline__ void load(const float *p, float (&v)[2])
+    {
+        const float2 t = *reinterpret_cast<const float2 *>(p);
+        v[0] = t.x; v[1] = t.y;
+    }
+};
+template <>
+struct VecLoad<4> {
+    static __device__ __forceinline__ void load(const float *p, float (&v)[4])
+    {
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+};
+
+constexpr uint32_t SCAN_QUEUES = 64;       // ticket counters (tile queues)
+constexpr uint32_t SCAN_TICKET_STRIDE = 64;   // ints between counters: atomics on one cache line serialise
+constexpr uint32_t SCAN_MAX_ROWS = 512;    // rows per tile; also the size of the pending-key list
+
+template <int V, int LL>
 __global__ __launch_bounds__(WAVE) void score_scan_kernel(
-    const float *__restrict__ scores, int N, int C, int rpl, float score_thr,
-    uint32_t tiles_per_image, int *__restrict__ cand_count, uint64_t *__restrict__ cand_keys,
-    uint32_t cand_stride)
+    const float *__restrict__ scores, int N, int C, ScanGeom g, float score_thr, uint32_t tiles_per_image,
+    uint32_t total_tiles, int *__restrict__ tile_ticket, int *__restrict__ cand_count,
+    uint64_t *__restrict__ cand_keys, uint32_t cand_stride, uint32_t nq_arg, uint32_t dbg)
 {
-    extern __shared__ __attribute__((aligned(16))) float s_tile[];
+    extern __shared__ __attribute__((aligned(16))) float s_buf[];
+    __shared__ uint64_t s_pend[SCAN_MAX_ROWS];          // candidate keys of the tile just reduced
+    constexpr uint32_t LPR = 1u << LL;                  // lanes per row
+    constexpr uint32_t G = WAVE >> LL;                  // rows per wave-step
     const uint32_t lane = threadIdx.x;
-    const uint32_t blk = blockIdx.x;
-    const uint32_t b = blk / tiles_per_image;
-    const uint32_t rows_per_tile = (uint32_t)rpl * WAVE;
-    const uint32_t n0 = (blk - b * tiles_per_image) * rows_per_tile;
-    const uint32_t rows = min(rows_per_tile, (uint32_t)N - n0);
-    const float *src = scores + ((size_t)b * N + n0) * (size_t)C;
-    const uint32_t nfloat = rows * (uint32_t)C;
+    const uint32_t sub = lane & (LPR - 1);
+    const uint32_t grp = lane >> LL;
+    const uint32_t R = (uint32_t)g.steps * G;
+    const uint32_t lds_base = lds_address(s_buf);
+    const uint32_t stride_k = LPR * V;                  // floats between a lane's consecutive reads
 
-    if (((uintptr_t)src & 15u) == 0)
-        dma_tile<4>(src, s_tile, nfloat, lane);
-    else
-        dma_tile<1>(src, s_tile, nfloat, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+    auto tile_origin = [&](uint32_t t, uint32_t &b, uint32_t &n0) {
+        divmod_u32(t, tiles_per_image, g.tpi_magic, b, n0);
+        n0 *= R;
+    };
+    auto issue = [&](uint32_t t, uint32_t which) {
+        uint32_t b, n0;
+        tile_origin(t, b, n0);
+        const uint32_t rows = min(R, (uint32_t)N - n0);
+        const float *src = scores + ((size_t)b * N + n0) * (size_t)C;
+        const uint32_t dst = lds_base + which * g.buf_floats * 4u;
+        if (((uintptr_t)src & 15u) == 0)
+            dma_tile<4>(src, dst, rows * (uint32_t)C, lane);
+        else
+            dma_tile<1>(src, dst, rows * (uint32_t)C, lane);
+    };
 
-    const uint32_t skew = (C & 1) ? 0u : 1u;       // lane stride C + skew is odd
-    for (int j = 0; j < rpl; ++j) {
-        const uint32_t r = (uint32_t)j * WAVE + lane;
-        const bool live = r < rows;
-        float best = -INFINITY;
-        uint32_t bcol = 0;
-        if (live) {
-            const float *rowp = s_tile + r * (uint32_t)C;
-            uint32_t col = (r * skew) % (uint32_t)C;
-            for (int k = 0; k < C; ++k) {
-                const float v = rowp[col];
-                const bool better = (v > best) || (v == best && col < bcol);
-                best = better ? v : best;
-                bcol = better ? col : bcol;
-                col = (col + 1 == (uint32_t)C) ? 0u : col + 1;
-            }
+    // Tiles are handed out by ticket counters: a workgroup that is not resident at launch finds
+    // its queue empty instead of stretching the tail.  One counter saturates near 88 tickets/us
+    // (MI355X_MICROARCH.md "dequeue"), far below the tile rate of this kernel, so the tile
+    // range is cut into SCAN_QUEUES contiguous queues with one counter (on its own cache line)
+    // each; block i draws from queue i % Q and its first tile is its rank i / Q in that queue.
+    // vmcnt retires in order, so anything that waits on a vector-memory result issued AFTER the
+    // prefetch DMAs would wait for the whole prefetch.  Hence: both returning atomics of an
+    // iteration (the ticket for the tile after next, the slot reservation for the candidates
+    // of the previous tile) are issued at the top, BEFORE the iteration's one s_waitcnt
+    // vmcnt(0), where only the current tile is outstanding; the DMAs of the next tile go out
+    // after it; and the reduce phase issues no vector-memory instruction at all.
+    const uint32_t nq = min(nq_arg, gridDim.x);                       // every queue has a block
+    const uint32_t q = blockIdx.x % nq;
+    const uint32_t q_lo = (uint32_t)(((uint64_t)total_tiles * q) / nq);
+    const uint32_t q_hi = (uint32_t)(((uint64_t)total_tiles * (q + 1)) / nq);
+    const uint32_t q_blocks = (gridDim.x - q + nq - 1) / nq;          // blocks drawing from queue q
+    int *my_ticket = tile_ticket + q * SCAN_TICKET_STRIDE;
+    auto draw = [&]() -> uint32_t {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(my_ticket, 1);
+        return q_lo + q_blocks + (uint32_t)__builtin_amdgcn_readfirstlane(v);
+    };
+    uint32_t t = q_lo + blockIdx.x / nq;
+    if (t >= q_hi) return;
+    issue(t, 0);
+    uint32_t nt = draw();
+    uint32_t pend_n = 0, pend_b = 0;
+
+    for (uint32_t it = 0;; ++it) {
+        const uint32_t nnt = nt < q_hi ? draw() : nt;                 // ticket for the tile after next
+        uint32_t slot = 0;
+        if (pend_n != 0) {
+            int v = 0;
+            if (lane == 0) v = atomicAdd(cand_count + pend_b * CNT_STRIDE, (int)pend_n);
+            slot = (uint32_t)__builtin_amdgcn_readfirstlane(v);
         }
-        const bool cand = live && (best > score_thr);                     // bndbox.py:205
-        const uint64_t mask = __ballot(cand);
-        if (mask) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(cand_count + b, (int)__popcll(mask));
-            base = __shfl(base, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // tile t has landed
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = lane; i < pend_n; i += WAVE)
+            if (slot + i < cand_stride) cand_keys[(size_t)pend_b * cand_stride + slot + i] = s_pend[i];
+        if (nt < q_hi && !(dbg & 2u)) issue(nt, (it + 1) & 1u);
+
+        // ---- reduce tile t out of LDS (no vector-memory instruction in here) ----------------
+        const float *buf = s_buf + (it & 1u) * g.buf_floats;
+        uint32_t b, n0;
+        tile_origin(t, b, n0);
+        const uint32_t rows = min(R, (uint32_t)N - n0);
+        const uint32_t nsteps = (dbg & 1u) ? 0u : (rows + G - 1) >> (6 - LL);
+        pend_n = 0;
+        pend_b = b;
+        for (uint32_t step = 0; step < nsteps; ++step) {
+            const uint32_t row = step * G + grp;
+            const bool live = row < rows;
+            // lanes past the last row read the last row (valid address) and drop the result
+            const float *rowp = buf + min(row, rows - 1) * (uint32_t)C + sub * V;
+            float m0 = -INFINITY, m1 = -INFINITY;
+            int k = 0;
+#pragma unroll 4
+            for (; k + 2 <= g.kfull; k += 2) {
+                float v0[V], v1[V];
+                VecLoad<V>::load(rowp + (uint32_t)k * stride_k, v0);
+                VecLoad<V>::load(rowp + (uint32_t)(k + 1) * stride_k, v1);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    m0 = fmaxf(m0, v0[e]);
+                    m1 = fmaxf(m1, v1[e]);
+                }
+            }
+            for (; k < g.K; ++k) {                       // odd read and the partial last read
+                const bool ok = ((uint32_t)k * LPR + sub) * V < (uint32_t)C;
+                float v0[V];
+                VecLoad<V>::load(ok ? rowp + (uint32_t)k * stride_k : rowp, v0);
+#pragma unroll
+                for (int e = 0; e < V; ++e) m0 = fmaxf(m0, ok ? v0[e] : -INFINITY);
+            }
+            const float m = group_max<LL>(fmaxf(m0, m1));
+            const bool cand = live && (m > score_thr);                          // bndbox.py:205
+            if (__ballot(cand) == 0ull) continue;                               // wave-uniform, common
+            // rare: find tf.argmax's FIRST maximal column of the candidate rows, queue the keys
+            uint32_t bcol = 0xffffffffu;
             if (cand) {
-                const uint32_t pos = (uint32_t)base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                if (pos < cand_stride)
-                    cand_keys[(size_t)b * cand_stride + pos] = cand_key(bcol, best, n0 + r);
+                for (int kk = 0; kk < g.K; ++kk) {
+                    const uint32_t col = ((uint32_t)kk * LPR + sub) * V;
+                    if (col < (uint32_t)C) {
+                        float v0[V];
+                        VecLoad<V>::load(rowp + (uint32_t)kk * stride_k, v0);
+#pragma unroll
+                        for (int e = V - 1; e >= 0; --e)
+                            if (v0[e] == m) bcol = min(bcol, col + (uint32_t)e);
+                    }
+                }
             }
+            bcol = group_min<LL>(bcol);
+            const uint64_t mask = __ballot(cand && sub == 0);
+            if (cand && sub == 0)
+                s_pend[pend_n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = cand_key(bcol, m, n0 + row);
+            pend_n += (uint32_t)__popcll(mask);
         }
+        if (nt >= q_hi) break;
+        t = nt;
+        nt = nnt;
+    }
+    if (pend_n != 0) {                                  // candidates of the last tile
+        int slot_raw = 0;
+        if (lane == 0) slot_raw = atomicAdd(cand_count + pend_b * CNT_STRIDE, (int)pend_n);
+        const uint32_t base = (uint32_t)__shfl(slot_raw, 0);
+        for (uint32_t i = lane; i < pend_n; i += WAVE)
+            if (base + i < cand_stride) cand_keys[(size_t)pend_b * cand_stride + base + i] = s_pend[i];
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// Block-wide bitonic sort of P (power of two) u64 keys, ascending, in LDS or global memory.
+// In-place ascending sort of n u64 keys (any n) with the "flip" bitonic network: every
+// compare-exchange moves the minimum to the lower index, so the virtual +inf padding above n
+// never moves and needs no storage.  BLOCK: all threads of the block, __syncthreads between
+// stages; otherwise the 64 lanes of one wave on wave-private memory.
 // ------------------------------------------------------------------------------------------
-constexpr int SORT_THREADS = 1024;
-constexpr uint32_t SORT_LDS_CAP = 16384;   // keys; 128 KiB of LDS
-
-__device__ void bitonic_sort(uint64_t *keys, uint32_t P)
-{
-    for (uint32_t k = 2; k <= P; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < (P >> 1); t += SORT_THREADS) {
-                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const uint32_t hi = lo | j;
-                const uint64_t x = keys[lo], y = keys[hi];
-                const bool asc = (lo & k) == 0;
-                if ((x > y) == asc) { keys[lo] = y; keys[hi] = x; }
-            }
-            __syncthreads();
-        }
-    }
-}
-
 __device__ __forceinline__ uint32_t next_pow2(uint32_t v)
 {
     uint32_t p = 1;
@@ -495,44 +653,167 @@ __device__ __forceinline__ uint32_t next_pow2(uint32_t v)
     return p;
 }
 
-// kernel 2: per image, sort the candidate keys (class asc, score desc, anchor asc) and record
-// where each class starts.  Optional pre-NMS top-k (extension, see odbox.h).
+template <bool BLOCK>
+__device__ __forceinline__ void sort_sync()
+{
+    if constexpr (BLOCK) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+template <bool BLOCK, typename KeyPtr>
+__device__ __forceinline__ void sort_u64(KeyPtr keys, uint32_t n, uint32_t tid, uint32_t nthreads)
+{
+    if (n < 2) return;
+    const uint32_t half = next_pow2(n) >> 1;
+    for (uint32_t k = 2; (k >> 1) <= half; k <<= 1) {
+        const uint32_t hk = k >> 1;
+        for (uint32_t t = tid; t < half; t += nthreads) {          // flip stage
+            const uint32_t base = (t & ~(hk - 1)) << 1, off = t & (hk - 1);
+            const uint32_t lo = base + off, hi = base + k - 1 - off;
+            if (hi < n) {
+                const uint64_t x = keys[lo], y = keys[hi];
+                if (x > y) { keys[lo] = y; keys[hi] = x; }
+            }
+        }
+        sort_sync<BLOCK>();
+        for (uint32_t j = hk >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < half; t += nthreads) {
+                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t hi = lo | j;
+                if (hi < n) {
+                    const uint64_t x = keys[lo], y = keys[hi];
+                    if (x > y) { keys[lo] = y; keys[hi] = x; }
+                }
+            }
+            sort_sync<BLOCK>();
+        }
+    }
+}
+
+// 64 keys, one per lane, sorted across the wave in registers (same network, shuffles)
+__device__ __forceinline__ uint64_t wave_sort64(uint64_t key, uint32_t lane)
+{
+    for (uint32_t k = 2; k <= WAVE; k <<= 1) {
+        {
+            const uint64_t other = __shfl(key, (int)(lane ^ (k - 1)));
+            const bool lower = (lane & (k >> 1)) == 0;
+            key = lower ? (other < key ? other : key) : (other > key ? other : key);
+        }
+        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+            const uint64_t other = __shfl(key, (int)(lane ^ j));
+            const bool lower = (lane & j) == 0;
+            key = lower ? (other < key ? other : key) : (other > key ? other : key);
+        }
+    }
+    return key;
+}
+
+constexpr int SORT_THREADS = 1024;
+constexpr uint32_t SORT_LDS_CAP = 16384;   // keys a block sorts in LDS (128 KiB); more: in global memory
+constexpr uint32_t NMS_SEG_LDS = 512;      // keys one NMS wave sorts by itself; bigger segments: block sort
+
+// kernel 2: counting sort of one image's candidate keys by class (LDS histogram -> scan ->
+// scatter).  Writes the class segment starts and flags the image for the block sort when one
+// class holds more keys than an NMS wave sorts on its own.
+constexpr int PART_THREADS = 512;
+
+__global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
+    const int *__restrict__ cand_count, const uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out,
+    uint32_t cand_stride, int C, int *__restrict__ seg_start, int *__restrict__ big_flag)
+{
+    extern __shared__ int s_hist[];      // [C] counts -> cursors, then [PART_THREADS] scan scratch
+    int *s_scan = s_hist + C;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t M = min((uint32_t)cand_count[b * CNT_STRIDE], cand_stride);
+    const uint64_t *in = keys_in + (size_t)b * cand_stride;
+    uint64_t *out = keys_out + (size_t)b * cand_stride;
+    for (int c = tid; c < C; c += PART_THREADS) s_hist[c] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < M; i += PART_THREADS) atomicAdd(&s_hist[key_class(in[i])], 1);
+    __syncthreads();
+    // exclusive scan over classes: each thread owns a contiguous chunk
+    const int chunk = (C + PART_THREADS - 1) / PART_THREADS;
+    const int c0 = min((int)tid * chunk, C), c1 = min(c0 + chunk, C);
+    int local = 0, biggest = 0;
+    for (int c = c0; c < c1; ++c) { local += s_hist[c]; biggest = max(biggest, s_hist[c]); }
+    s_scan[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < PART_THREADS; off <<= 1) {
+        const int v = tid >= (uint32_t)off ? s_scan[tid - off] : 0;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    int run = s_scan[tid] - local;
+    int *seg = seg_start + (size_t)b * (C + 1);
+    for (int c = c0; c < c1; ++c) {
+        const int cnt = s_hist[c];
+        seg[c] = run;
+        s_hist[c] = run;                 // becomes the scatter cursor
+        run += cnt;
+    }
+    if (tid == 0) seg[C] = (int)M;
+    if (biggest > (int)NMS_SEG_LDS) atomicOr(big_flag + b, 1);
+    __syncthreads();
+    for (uint32_t i = tid; i < M; i += PART_THREADS) {
+        const uint64_t k = in[i];
+        out[atomicAdd(&s_hist[key_class(k)], 1)] = k;
+    }
+}
+
+// kernel 2b: block sort of a whole image's candidate list.
+//   mode 0 (pre-NMS top-k requested): keep the best pre_nms_topk keys by (score desc, anchor
+//          asc), sort them (class asc, score desc, anchor asc), write the segment starts.
+//   mode 1: only images flagged by the partition kernel (a class segment too long for one
+//          wave); the list is already grouped by class, sorting it fully orders every segment.
 __global__ __launch_bounds__(SORT_THREADS) void cand_sort_kernel(
     int *__restrict__ cand_count, uint64_t *__restrict__ cand_keys, uint32_t cand_stride, int C,
-    int pre_nms_topk, int *__restrict__ seg_start)
+    int pre_nms_topk, int mode, int *__restrict__ seg_start, int *__restrict__ big_flag)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
     const uint32_t b = blockIdx.x;
+    if (mode == 1 && big_flag[b] == 0) return;
     uint64_t *gk = cand_keys + (size_t)b * cand_stride;
-    uint32_t M = min((uint32_t)cand_count[b], cand_stride);
-    uint32_t P = max(next_pow2(M), 2u);
-    const bool in_lds = P <= SORT_LDS_CAP;
-    uint64_t *k = in_lds ? s_keys : gk;
-
-    const bool topk = pre_nms_topk > 0 && M > (uint32_t)pre_nms_topk;
-    for (uint32_t i = threadIdx.x; i < P; i += SORT_THREADS) {
-        uint64_t v = i < M ? gk[i] : ~0ull;
-        if (topk && i < M) v = cand_to_topk(v);
-        k[i] = v;
-    }
-    __syncthreads();
-    if (topk) {
-        bitonic_sort(k, P);
-        const uint32_t keep = (uint32_t)pre_nms_topk;
-        for (uint32_t i = threadIdx.x; i < P; i += SORT_THREADS) k[i] = i < keep ? topk_to_cand(k[i]) : ~0ull;
-        M = keep;
-        __syncthreads();
-    }
-    bitonic_sort(k, P);
-
-    int *seg = seg_start + (size_t)b * (C + 1);
-    for (uint32_t i = threadIdx.x; i <= M; i += SORT_THREADS) {
-        if (i < M && in_lds) gk[i] = k[i];
-        const int c_hi = i < M ? (int)key_class(k[i]) : C;
-        const int c_lo = i > 0 ? (int)key_class(k[i - 1]) + 1 : 0;
-        for (int c = c_lo; c <= min(c_hi, C); ++c) seg[c] = (int)i;
-    }
-    if (threadIdx.x == 0) cand_count[b] = (int)M;
+    const uint32_t M0 = min((uint32_t)cand_count[b * CNT_STRIDE], cand_stride);
+    const bool topk = mode == 0 && pre_nms_topk > 0 && M0 > (uint32_t)pre_nms_topk;
+    // one instantiation per address space: LDS (ds_*) or global memory, never flat
+    auto run = [&](auto k, bool staged) {
+        uint32_t M = M0;
+        if (staged || topk) {
+            for (uint32_t i = threadIdx.x; i < M; i += SORT_THREADS) k[i] = topk ? cand_to_topk(gk[i]) : gk[i];
+            __syncthreads();
+        }
+        if (topk) {
+            sort_u64<true>(k, M, threadIdx.x, SORT_THREADS);
+            M = (uint32_t)pre_nms_topk;
+            for (uint32_t i = threadIdx.x; i < M; i += SORT_THREADS) k[i] = topk_to_cand(k[i]);
+            __syncthreads();
+        }
+        sort_u64<true>(k, M, threadIdx.x, SORT_THREADS);
+        if (staged)
+            for (uint32_t i = threadIdx.x; i < M; i += SORT_THREADS) gk[i] = k[i];
+        if (mode == 0) {
+            int *seg = seg_start + (size_t)b * (C + 1);
+            for (uint32_t i = threadIdx.x; i <= M; i += SORT_THREADS) {
+                const int c_hi = i < M ? (int)key_class(k[i]) : C;
+                const int c_lo = i > 0 ? (int)key_class(k[i - 1]) + 1 : 0;
+                for (int c = c_lo; c <= min(c_hi, C); ++c) seg[c] = (int)i;
+            }
+            if (threadIdx.x == 0) {
+                cand_count[b * CNT_STRIDE] = (int)M;
+                big_flag[b] = 1;         // every segment is already in visiting order
+            }
+        }
+    };
+    if (M0 <= SORT_LDS_CAP)
+        run(s_keys, true);
+    else
+        run(gk, false);
 }
 
 // decoded (+ clipped) box of anchor `idx` of image b: bndbox.py:88-99, :105-115
@@ -557,17 +838,26 @@ __device__ __forceinline__ float nms_iou(const float4 p, float pa, const float4 
     return inter / ((pa + qa) - inter);
 }
 
-// kernel 3: greedy NMS, one wave per (image, class) segment of the sorted candidate list.
-// The kept list (<= max_ret boxes) lives in LDS; candidates are taken 64 at a time: first
-// tested against the kept list, then resolved inside the chunk with ballots (the lowest live
-// lane is kept and suppresses the lanes above it).  Stops at max_ret kept (bndbox.py:172).
+// value of lane j (wave-uniform j) through an SGPR (v_readlane_b32), no LDS crossbar trip
+__device__ __forceinline__ float bcast_lane(float v, int j)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
+
+// kernel 3: greedy NMS, one wave per (image, class) segment.  The wave first puts its segment
+// in visiting order (score desc, anchor asc): <= 64 keys in registers, <= NMS_SEG_LDS keys in
+// its own LDS, longer segments were sorted by cand_sort_kernel.  The kept list (<= max_ret
+// boxes) lives in LDS; candidates are taken 64 at a time: tested against the kept list, then
+// resolved inside the chunk with ballots (the lowest live lane is kept and suppresses the lanes
+// above it).  Stops at max_ret kept (bndbox.py:172).
 constexpr int NMS_WAVES = 4;
 
 __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
     const float4 *__restrict__ anchors, const float4 *__restrict__ rb, int N, int C, int do_clip,
     float hi_x, float hi_y, float iou_thr, int max_ret, const uint64_t *__restrict__ cand_keys,
-    uint32_t cand_stride, const int *__restrict__ seg_start, int *__restrict__ fin_count,
-    uint64_t *__restrict__ fin_keys, uint32_t fin_stride, uint32_t total_segments, int waves_per_block)
+    uint32_t cand_stride, const int *__restrict__ seg_start, const int *__restrict__ big_flag,
+    int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys, uint32_t fin_stride,
+    uint32_t total_segments, int waves_per_block, uint32_t per_wave_bytes, uint32_t dbg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const uint32_t lane = threadIdx.x & 63u;
@@ -579,20 +869,35 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
     const int start = seg_start[(size_t)b * (C + 1) + c];
     const int end = seg_start[(size_t)b * (C + 1) + c + 1];
     if (end <= start) return;
+    const uint32_t m = (uint32_t)(end - start);
 
-    // per-wave LDS: max_ret boxes (float4) + max_ret areas + max_ret keys
-    const size_t per_wave = (size_t)max_ret * (16 + 4 + 8);
-    unsigned char *mine = s_raw + wave * ((per_wave + 15) & ~(size_t)15);
+    unsigned char *mine = s_raw + (size_t)wave * per_wave_bytes;
     float4 *s_box = reinterpret_cast<float4 *>(mine);
     uint64_t *s_key = reinterpret_cast<uint64_t *>(mine + (size_t)max_ret * 16);
     float *s_area = reinterpret_cast<float *>(mine + (size_t)max_ret * 24);
+    uint64_t *s_sort = reinterpret_cast<uint64_t *>(mine + (((size_t)max_ret * 28 + 15) & ~(size_t)15));
 
-    const uint64_t *keys = cand_keys + (size_t)b * cand_stride;
+    const uint64_t *keys = cand_keys + (size_t)b * cand_stride + start;
+    const bool presorted = big_flag[b] != 0;
+    uint64_t reg_key = ~0ull;
+    const uint64_t *sorted = keys;
+    if (!presorted && !(dbg & 1u)) {
+        if (m <= WAVE) {
+            reg_key = wave_sort64(lane < m ? keys[lane] : ~0ull, lane);
+        } else {                                    // m <= NMS_SEG_LDS by the partition kernel's flag
+            for (uint32_t i = lane; i < m; i += WAVE) s_sort[i] = keys[i];
+            sort_sync<false>();
+            sort_u64<false>(s_sort, m, lane, WAVE);
+            sorted = s_sort;
+        }
+    }
+
     int kept = 0;
-    for (int base = start; base < end && kept < max_ret; base += WAVE) {
-        const int i = base + (int)lane;
-        const bool valid = i < end;
-        const uint64_t key = valid ? keys[i] : 0ull;
+    for (uint32_t base = 0; base < m && kept < max_ret && !(dbg & 2u); base += WAVE) {
+        const uint32_t i = base + lane;
+        const bool valid = i < m;
+        uint64_t key = 0ull;
+        if (valid) key = (!presorted && m <= WAVE && !(dbg & 1u)) ? reg_key : sorted[i];
         float4 nb = make_float4(0.f, 0.f, 0.f, 0.f);
         float area = 0.0f;
         if (valid) {
@@ -608,8 +913,8 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
         uint64_t mask = __ballot(alive);
         while (mask != 0ull && kept < max_ret) {
             const int j = __ffsll((unsigned long long)mask) - 1;
-            const float4 jb = make_float4(__shfl(nb.x, j), __shfl(nb.y, j), __shfl(nb.z, j), __shfl(nb.w, j));
-            const float ja = __shfl(area, j);
+            const float4 jb = make_float4(bcast_lane(nb.x, j), bcast_lane(nb.y, j), bcast_lane(nb.z, j), bcast_lane(nb.w, j));
+            const float ja = bcast_lane(area, j);
             if ((int)lane == j) {
                 s_box[kept] = nb;
                 s_area[kept] = area;
@@ -619,12 +924,12 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
             if (alive && (int)lane > j && nms_iou(nb, area, jb, ja) > iou_thr) alive = false;
             mask = __ballot(alive) & ~((2ull << j) - 1ull);
         }
-        __builtin_amdgcn_wave_barrier();
+        sort_sync<false>();
     }
 
     // append this segment's kept keys to the image's final list (order fixed by the next sort)
     int out_base = 0;
-    if (lane == 0) out_base = atomicAdd(fin_count + b, kept);
+    if (lane == 0) out_base = atomicAdd(fin_count + b * CNT_STRIDE, kept);
     out_base = __shfl(out_base, 0);
     for (int k = (int)lane; k < kept; k += WAVE) {
         const uint32_t pos = (uint32_t)(out_base + k);
@@ -634,7 +939,9 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
 
 // kernel 4: per image, order the kept detections like tf.math.top_k over the class-ordered
 // concat (bndbox.py:220-229), emit the first max_ret and zero-pad the rest (:233-244).
-__global__ __launch_bounds__(SORT_THREADS) void finalize_kernel(
+constexpr int FIN_THREADS = 256;
+
+__global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
     const float4 *__restrict__ anchors, const float4 *__restrict__ rb, int N, int do_clip, float hi_x,
     float hi_y, int max_ret, const int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys,
     uint32_t fin_stride, float4 *__restrict__ out_boxes, float *__restrict__ out_scores,
@@ -643,72 +950,147 @@ __global__ __launch_bounds__(SORT_THREADS) void finalize_kernel(
     extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
     const uint32_t b = blockIdx.x;
     uint64_t *gk = fin_keys + (size_t)b * fin_stride;
-    const uint32_t n = min((uint32_t)fin_count[b], fin_stride);
-    const uint32_t P = max(next_pow2(n), 2u);
-    const bool in_lds = P <= SORT_LDS_CAP;
-    uint64_t *k = in_lds ? s_keys : gk;
-    for (uint32_t i = threadIdx.x; i < P; i += SORT_THREADS) k[i] = i < n ? gk[i] : ~0ull;
-    __syncthreads();
-    if (n > 1) bitonic_sort(k, P);
-
+    const uint32_t n = min((uint32_t)fin_count[b * CNT_STRIDE], fin_stride);
     const uint32_t keep = min(n, (uint32_t)max_ret);
-    for (uint32_t r = threadIdx.x; r < (uint32_t)max_ret; r += SORT_THREADS) {
-        const size_t o = (size_t)b * max_ret + r;
-        if (r < keep) {
-            const uint64_t ck = final_to_cand(k[r]);
-            const uint32_t idx = key_anchor(ck);
-            out_boxes[o] = candidate_box(anchors, rb, b, N, idx, do_clip, hi_x, hi_y);
-            out_scores[o] = key_score(ck);
-            out_labels[o] = (int32_t)key_class(ck);
-            if (out_keep) out_keep[o] = (int32_t)idx;
-        } else {
-            out_boxes[o] = make_float4(0.f, 0.f, 0.f, 0.f);
-            out_scores[o] = 0.0f;
-            out_labels[o] = 0;
-            if (out_keep) out_keep[o] = -1;
+    auto run = [&](auto k, bool staged) {
+        if (staged) {
+            for (uint32_t i = threadIdx.x; i < n; i += FIN_THREADS) k[i] = gk[i];
+            __syncthreads();
         }
-    }
+        sort_u64<true>(k, n, threadIdx.x, FIN_THREADS);
+        for (uint32_t r = threadIdx.x; r < (uint32_t)max_ret; r += FIN_THREADS) {
+            const size_t o = (size_t)b * max_ret + r;
+            if (r < keep) {
+                const uint64_t ck = final_to_cand(k[r]);
+                const uint32_t idx = key_anchor(ck);
+                out_boxes[o] = candidate_box(anchors, rb, b, N, idx, do_clip, hi_x, hi_y);
+                out_scores[o] = key_score(ck);
+                out_labels[o] = (int32_t)key_class(ck);
+                if (out_keep) out_keep[o] = (int32_t)idx;
+            } else {
+                out_boxes[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+                out_scores[o] = 0.0f;
+                out_labels[o] = 0;
+                if (out_keep) out_keep[o] = -1;
+            }
+        }
+    };
+    if (n <= SORT_LDS_CAP)
+        run(s_keys, true);
+    else
+        run(gk, false);
     if (out_count && threadIdx.x == 0) out_count[b] = (int32_t)keep;
 }
 
 // ------------------------------------------------------------------------------------------
-// workspace layout of odbox_decode_nms
+// workspace layout + launch geometry of odbox_decode_nms
 // ------------------------------------------------------------------------------------------
 struct NmsLayout {
-    size_t off_counts, off_seg, off_cand, off_fin, total;
+    size_t off_counts, off_tickets, off_seg, off_keys_a, off_keys_b, off_fin, total;
     uint32_t cand_stride, fin_stride;
-    int rpl;
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-inline uint32_t host_next_pow2(uint32_t v)
-{
-    uint32_t p = 1;
-    while (p < v) p <<= 1;
-    return p;
-}
 
 bool nms_layout(int B, int N, int C, int max_ret, NmsLayout &L)
 {
     if (B < 1 || N < 1 || C < 1 || max_ret < 1) return false;
     if (N > ODBOX_MAX_ANCHORS || C > ODBOX_MAX_CLASSES || max_ret > ODBOX_MAX_RET) return false;
-    // strides are powers of two whenever the global-memory sort could be taken
-    L.cand_stride = (uint32_t)N > SORT_LDS_CAP ? host_next_pow2((uint32_t)N) : (uint32_t)(N < 2 ? 2 : N);
+    L.cand_stride = (uint32_t)N;
     uint64_t fin = (uint64_t)C * (uint64_t)max_ret;
     if (fin > (uint64_t)N) fin = (uint64_t)N;
-    L.fin_stride = fin > SORT_LDS_CAP ? host_next_pow2((uint32_t)fin) : (uint32_t)(fin < 2 ? 2 : fin);
-    L.off_counts = 0;
-    L.off_seg = align_up((size_t)2 * B * sizeof(int), 256);
-    L.off_cand = L.off_seg + align_up((size_t)B * (C + 1) * sizeof(int), 256);
-    L.off_fin = L.off_cand + align_up((size_t)B * L.cand_stride * sizeof(uint64_t), 256);
+    L.fin_stride = (uint32_t)fin;
+    L.off_counts = 0;                                              // cand_count, fin_count (one 256-byte line per image), big_flag[B]; then the tile tickets
+    L.off_tickets = ((size_t)2 * B * CNT_STRIDE + align_up((size_t)B, 64)) * sizeof(int);
+    L.off_seg = L.off_tickets + (size_t)SCAN_QUEUES * SCAN_TICKET_STRIDE * sizeof(int);
+    L.off_keys_a = L.off_seg + align_up((size_t)B * (C + 1) * sizeof(int), 256);
+    L.off_keys_b = L.off_keys_a + align_up((size_t)B * L.cand_stride * sizeof(uint64_t), 256);
+    L.off_fin = L.off_keys_b + align_up((size_t)B * L.cand_stride * sizeof(uint64_t), 256);
     L.total = L.off_fin + align_up((size_t)B * L.fin_stride * sizeof(uint64_t), 256);
-    // rows per lane of the score scan: aim at ~16-24 KiB of LDS per wave
-    int rpl = 96 / C;
-    L.rpl = rpl < 1 ? 1 : (rpl > 8 ? 8 : rpl);
     return true;
 }
 
-constexpr int SCAN_MAX_CLASSES_LDS = 512;   // 64 rows * 512 classes * 4 B = 128 KiB
+// worst number of lanes of one LDS lane group that land on one bank with different addresses,
+// for lane l reading V dwords at (l >> LL) * C + (l & (LPR-1)) * V  (MI355X_MICROARCH.md, LDS)
+int scan_bank_conflict(int C, int V, int LL)
+{
+    static const int g128[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                    {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                    {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                    {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+    const int nbanks = V == 1 ? 32 : 64, lpr = 1 << LL;
+    const int ngroups = V == 4 ? 4 : 2, glen = V == 4 ? 16 : 32;
+    int worst = 1;
+    for (int gi = 0; gi < ngroups; ++gi) {
+        int hits[64] = {0};
+        for (int i = 0; i < glen; ++i) {
+            const int l = V == 4 ? g128[gi][i] : gi * 32 + i;
+            const long addr = (long)(l >> LL) * C + (long)(l & (lpr - 1)) * V;
+            for (int e = 0; e < V; ++e) {
+                const int bank = (int)((addr + e) % nbanks);
+                if (++hits[bank] > worst) worst = hits[bank];
+            }
+        }
+    }
+    return worst;
+}
+
+ScanGeom scan_geometry(int C, int N)
+{
+    ScanGeom g;
+    g.V = (C % 4 == 0) ? 4 : (C % 2 == 0) ? 2 : 1;
+    const int nvec = C / g.V;
+    // Lanes per row: as FEW as possible (fewest instructions per row: no cross-lane reduction,
+    // no per-step overhead) while the LDS reads stay at most 2-way bank conflicted, the lanes
+    // stay >= 85 % busy and one wave-step (64 / LPR rows) stays <= 16 KiB of LDS.
+    int pick = -1;
+    for (int l = 0; l <= 6 && pick < 0; ++l) {
+        const int lpr = 1 << l, K = (nvec + lpr - 1) / lpr;
+        const double eff = (double)nvec / ((double)K * lpr);
+        const size_t step_bytes = (size_t)(WAVE >> l) * C * sizeof(float);
+        if (eff >= 0.85 && scan_bank_conflict(C, g.V, l) <= 2 && step_bytes <= 16 * 1024) pick = l;
+    }
+    if (pick < 0) {                    // very wide rows: keep the step small, take the best lane use
+        double best = -1.0;
+        for (int l = 0; l <= 6; ++l) {
+            const int lpr = 1 << l, K = (nvec + lpr - 1) / lpr;
+            const double score = (double)nvec / ((double)K * lpr) / scan_bank_conflict(C, g.V, l);
+            const size_t step_bytes = (size_t)(WAVE >> l) * C * sizeof(float);
+            if ((step_bytes <= 16 * 1024 || l == 6) && score > best) { best = score; pick = l; }
+        }
+    }
+    g.lpr_log2 = pick;
+    if (const char *e = getenv("ODBOX_SCAN_LPR_LOG2")) g.lpr_log2 = atoi(e) >= 0 && atoi(e) <= 6 ? atoi(e) : g.lpr_log2;
+    const int lpr = 1 << g.lpr_log2;
+    g.K = (nvec + lpr - 1) / lpr;
+    g.kfull = nvec / lpr;
+    const int rows_per_step = WAVE / lpr;
+    const size_t step_bytes = (size_t)rows_per_step * C * sizeof(float);
+    int steps = (int)((12 * 1024) / step_bytes);                       // ~12 KiB per tile
+    const int max_steps = (int)SCAN_MAX_ROWS / rows_per_step;
+    g.steps = steps < 1 ? 1 : (steps > max_steps ? max_steps : steps);
+    if (const char *e = getenv("ODBOX_SCAN_STEPS")) g.steps = atoi(e) > 0 ? atoi(e) : g.steps;
+    if (g.steps > max_steps) g.steps = max_steps;
+    g.buf_floats = (uint32_t)align_up((size_t)g.steps * rows_per_step * C, 4);
+    const uint32_t R = (uint32_t)g.steps * rows_per_step;
+    const uint32_t tpi = ((uint32_t)N + R - 1) / R;
+    g.tpi_magic = tpi == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / tpi);
+    return g;
+}
+
+int device_cu_count()
+{
+    static thread_local int cached_dev = -1, cached_cus = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        cached_dev = dev;
+        cached_cus = cus;
+    }
+    return cached_cus;
+}
 
 // dynamic LDS above the 64 KiB default needs an explicit opt-in per kernel
 template <typename K>
@@ -717,6 +1099,52 @@ int allow_lds(K kernel, size_t bytes)
     if (bytes <= 48 * 1024) return 0;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return 0;
+}
+
+template <int V, int LL>
+int launch_scan_inst(const float *scores, int B, int N, int C, const ScanGeom &g, float score_thr, int *tile_ticket,
+                     int *cand_count, uint64_t *cand_keys, uint32_t cand_stride, hipStream_t st)
+{
+    const uint32_t R = (uint32_t)g.steps * (WAVE >> LL);
+    const uint64_t tiles = ((uint64_t)N + R - 1) / R;
+    const uint64_t total = tiles * (uint64_t)B;
+    if (total > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_decode_nms: too many score tiles");
+    const size_t lds = (size_t)2 * g.buf_floats * sizeof(float);
+    if (lds + SCAN_MAX_ROWS * 8 > 160 * 1024)
+        return fail(ODBOX_EINVAL, "odbox_decode_nms: C=%d needs %zu bytes of LDS per wave", C, lds);
+    int per_cu = (int)((160 * 1024) / align_up(lds + SCAN_MAX_ROWS * 8, 1024));
+    per_cu = per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu);
+    if (const char *e = getenv("ODBOX_SCAN_WAVES_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;   // tuning aid
+    uint32_t nq = SCAN_QUEUES, dbg = 0;
+    if (const char *e = getenv("ODBOX_SCAN_QUEUES")) nq = atoi(e) > 0 && atoi(e) <= (int)SCAN_QUEUES ? atoi(e) : nq;
+    if (const char *e = getenv("ODBOX_SCAN_DBG")) dbg = (uint32_t)atoi(e);
+    const uint64_t resident = (uint64_t)device_cu_count() * per_cu;
+    const uint32_t grid = (uint32_t)(total < resident ? total : resident);
+    if (int rc = allow_lds(score_scan_kernel<V, LL>, lds)) return rc;
+    hipLaunchKernelGGL((score_scan_kernel<V, LL>), dim3(grid), dim3(WAVE), lds, st, scores, N, C, g, score_thr,
+                       (uint32_t)tiles, (uint32_t)total, tile_ticket, cand_count, cand_keys, cand_stride, nq, dbg);
+    return launch_status("score_scan");
+}
+
+template <int V>
+int launch_scan(const float *scores, int B, int N, int C, const ScanGeom &g, float score_thr, int *tile_ticket,
+                int *cand_count, uint64_t *cand_keys, uint32_t cand_stride, hipStream_t st)
+{
+#define ODBOX_SCAN_CASE(LL)                                                                                  \
+    case LL:                                                                                                 \
+        return launch_scan_inst<V, LL>(scores, B, N, C, g, score_thr, tile_ticket, cand_count, cand_keys,    \
+                                       cand_stride, st)
+    switch (g.lpr_log2) {
+        ODBOX_SCAN_CASE(0);
+        ODBOX_SCAN_CASE(1);
+        ODBOX_SCAN_CASE(2);
+        ODBOX_SCAN_CASE(3);
+        ODBOX_SCAN_CASE(4);
+        ODBOX_SCAN_CASE(5);
+        ODBOX_SCAN_CASE(6);
+    }
+#undef ODBOX_SCAN_CASE
+    return fail(ODBOX_EINVAL, "odbox_decode_nms: bad scan geometry");
 }
 
 }  // namespace
@@ -860,16 +1288,14 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
                      int32_t *out_keep_anchor, int32_t *out_count, void *workspace, size_t workspace_bytes,
                      void *stream)
 {
+    if (B == 0) return 0;
     if (!regress_or_boxes || !scores || !out_boxes || !out_scores || !out_labels)
         return fail(ODBOX_EINVAL, "odbox_decode_nms: NULL pointer");
-    if (B == 0) return 0;
     NmsLayout L;
     if (!nms_layout(B, N, C, max_ret, L))
         return fail(ODBOX_EINVAL,
                     "odbox_decode_nms: bad shape B=%d N=%d C=%d max_ret=%d (limits: N<=%d C<=%d max_ret<=%d)", B, N, C,
                     max_ret, ODBOX_MAX_ANCHORS, ODBOX_MAX_CLASSES, ODBOX_MAX_RET);
-    if (C > SCAN_MAX_CLASSES_LDS)
-        return fail(ODBOX_EINVAL, "odbox_decode_nms: C=%d exceeds the score-scan tile limit %d", C, SCAN_MAX_CLASSES_LDS);
     if (pre_nms_topk < 0) return fail(ODBOX_EINVAL, "odbox_decode_nms: pre_nms_topk < 0");
     if (!workspace || workspace_bytes < L.total)
         return fail(ODBOX_ENOSPC, "odbox_decode_nms: workspace %zu bytes, need %zu", workspace_bytes, L.total);
@@ -881,46 +1307,60 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
     hipStream_t st = (hipStream_t)stream;
     unsigned char *ws = (unsigned char *)workspace;
     int *cand_count = (int *)(ws + L.off_counts);
-    int *fin_count = cand_count + B;
+    int *fin_count = cand_count + (size_t)B * CNT_STRIDE;
+    int *big_flag = cand_count + (size_t)2 * B * CNT_STRIDE;
+    int *tile_ticket = (int *)(ws + L.off_tickets);
     int *seg_start = (int *)(ws + L.off_seg);
-    uint64_t *cand_keys = (uint64_t *)(ws + L.off_cand);
+    uint64_t *keys_a = (uint64_t *)(ws + L.off_keys_a);
+    uint64_t *keys_b = (uint64_t *)(ws + L.off_keys_b);
     uint64_t *fin_keys = (uint64_t *)(ws + L.off_fin);
     const float hi_x = img_w - 1.0f, hi_y = img_h - 1.0f;
 
-    HIP_TRY(hipMemsetAsync(cand_count, 0, (size_t)2 * B * sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(ws, 0, L.off_seg, st));      // counters, flags, tile tickets
 
-    // kernel 1: score scan
-    const uint32_t rows_per_tile = (uint32_t)L.rpl * WAVE;
-    const uint64_t tiles = ((uint64_t)N + rows_per_tile - 1) / rows_per_tile;
-    if (tiles * B > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_decode_nms: grid too large");
-    const size_t scan_lds = (size_t)rows_per_tile * C * sizeof(float);
-    if (int rc = allow_lds(score_scan_kernel, scan_lds)) return rc;
-    hipLaunchKernelGGL(score_scan_kernel, dim3((uint32_t)(tiles * B)), dim3(WAVE), scan_lds, st, scores, N, C, L.rpl,
-                       score_thr, (uint32_t)tiles, cand_count, cand_keys, L.cand_stride);
-    if (int rc = launch_status("score_scan")) return rc;
+    // kernel 1: score scan -> unordered candidate keys per image
+    const ScanGeom g = scan_geometry(C, N);
+    int rc = g.V == 4 ? launch_scan<4>(scores, B, N, C, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, st)
+           : g.V == 2 ? launch_scan<2>(scores, B, N, C, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, st)
+                      : launch_scan<1>(scores, B, N, C, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, st);
+    if (rc) return rc;
 
-    // kernel 2: per-image candidate sort + class segment starts
-    const size_t sort_lds = (size_t)(L.cand_stride < SORT_LDS_CAP ? host_next_pow2(L.cand_stride) : SORT_LDS_CAP) * 8;
-    if (int rc = allow_lds(cand_sort_kernel, sort_lds)) return rc;
-    hipLaunchKernelGGL(cand_sort_kernel, dim3(B), dim3(SORT_THREADS), sort_lds, st, cand_count, cand_keys,
-                       L.cand_stride, C, pre_nms_topk, seg_start);
-    if (int rc = launch_status("cand_sort")) return rc;
+    // kernel 2: group by class (counting sort), or the full block sort when a top-k is requested
+    const size_t sort_lds = (size_t)(L.cand_stride < SORT_LDS_CAP ? L.cand_stride : SORT_LDS_CAP) * 8;
+    if (int r2 = allow_lds(cand_sort_kernel, sort_lds)) return r2;
+    const uint64_t *nms_keys;
+    if (pre_nms_topk > 0) {
+        hipLaunchKernelGGL(cand_sort_kernel, dim3(B), dim3(SORT_THREADS), sort_lds, st, cand_count, keys_a,
+                           L.cand_stride, C, pre_nms_topk, 0, seg_start, big_flag);
+        if (int r2 = launch_status("cand_sort")) return r2;
+        nms_keys = keys_a;
+    } else {
+        const size_t part_lds = (size_t)(C + PART_THREADS) * sizeof(int);
+        hipLaunchKernelGGL(cand_partition_kernel, dim3(B), dim3(PART_THREADS), part_lds, st, cand_count, keys_a, keys_b,
+                           L.cand_stride, C, seg_start, big_flag);
+        if (int r2 = launch_status("cand_partition")) return r2;
+        hipLaunchKernelGGL(cand_sort_kernel, dim3(B), dim3(SORT_THREADS), sort_lds, st, cand_count, keys_b,
+                           L.cand_stride, C, 0, 1, seg_start, big_flag);
+        if (int r2 = launch_status("cand_sort")) return r2;
+        nms_keys = keys_b;
+    }
 
     // kernel 3: per-(image, class) greedy NMS
-    const size_t per_wave = align_up((size_t)max_ret * 28, 16);
+    const size_t per_wave = align_up((size_t)max_ret * 28, 16) + (size_t)NMS_SEG_LDS * 8;
     const int waves = per_wave * NMS_WAVES <= 64 * 1024 ? NMS_WAVES : 1;
     const uint64_t segs = (uint64_t)B * C;
-    if (int rc = allow_lds(nms_kernel, per_wave * waves)) return rc;
+    if (int r3 = allow_lds(nms_kernel, per_wave * waves)) return r3;
     hipLaunchKernelGGL(nms_kernel, dim3((uint32_t)((segs + waves - 1) / waves)), dim3(waves * WAVE), per_wave * waves,
                        st, (const float4 *)anchors, (const float4 *)regress_or_boxes, N, C, do_clip, hi_x, hi_y,
-                       iou_thr, max_ret, cand_keys, L.cand_stride, seg_start, fin_count, fin_keys, L.fin_stride,
-                       (uint32_t)segs, waves);
-    if (int rc = launch_status("nms")) return rc;
+                       iou_thr, max_ret, nms_keys, L.cand_stride, seg_start, big_flag, fin_count, fin_keys,
+                       L.fin_stride, (uint32_t)segs, waves, (uint32_t)per_wave,
+                       (uint32_t)(getenv("ODBOX_NMS_DBG") ? atoi(getenv("ODBOX_NMS_DBG")) : 0));
+    if (int r3 = launch_status("nms")) return r3;
 
     // kernel 4: final order, top max_ret, zero padding
-    const size_t fin_lds = (size_t)(L.fin_stride < SORT_LDS_CAP ? host_next_pow2(L.fin_stride) : SORT_LDS_CAP) * 8;
-    if (int rc = allow_lds(finalize_kernel, fin_lds)) return rc;
-    hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(SORT_THREADS), fin_lds, st, (const float4 *)anchors,
+    const size_t fin_lds = (size_t)(L.fin_stride < SORT_LDS_CAP ? L.fin_stride : SORT_LDS_CAP) * 8;
+    if (int r4 = allow_lds(finalize_kernel, fin_lds)) return r4;
+    hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(FIN_THREADS), fin_lds, st, (const float4 *)anchors,
                        (const float4 *)regress_or_boxes, N, do_clip, hi_x, hi_y, max_ret, fin_count, fin_keys,
                        L.fin_stride, (float4 *)out_boxes, out_scores, out_labels, out_keep_anchor, out_count);
     return launch_status("finalize");
