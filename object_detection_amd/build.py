@@ -10,16 +10,23 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = os.path.join(HERE, 'csrc', 'odbox.hip')
+CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libodbox.so')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-shared', '-std=c++17',
-         '-I' + os.path.join(ROOT, 'include')]
+OBJ = os.path.join(HERE, 'build')
+COMMON = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-std=c++17',
+          '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
+# translation unit -> extra flags (see the header comment of each file)
+UNITS = {
+    'odbox_train.hip': [],
+    'odbox_infer.hip': ['-fno-honor-nans'],
+}
+HEADERS = [os.path.join(CSRC, 'odbox_common.h'), os.path.join(ROOT, 'include', 'odbox.h')]
 
 
 def needs_build():
     if not os.path.exists(OUT):
         return True
-    deps = [SRC, os.path.join(ROOT, 'include', 'odbox.h')]
+    deps = HEADERS + [os.path.join(CSRC, u) for u in UNITS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
 
 
@@ -27,7 +34,16 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get('HIPCC', 'hipcc')
-    cmd = [hipcc] + FLAGS + ['-o', OUT, SRC]
+    os.makedirs(OBJ, exist_ok=True)
+    objs = []
+    for unit, extra in UNITS.items():
+        obj = os.path.join(OBJ, unit.replace('.hip', '.o'))
+        cmd = [hipcc] + COMMON + extra + ['-c', os.path.join(CSRC, unit), '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)

@@ -1,382 +1,17 @@
-// odbox.hip -- hand-written gfx950 (MI355X, wave64) kernels + the C-ABI of include/odbox.h.
+// odbox_infer.hip -- inference-side kernels (score scan, candidate partition / sort, per-class
+// greedy NMS, final top-k) + odbox_decode_nms (include/odbox.h), gfx950 / wave64.
 //
-// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see build.py).
-// -ffp-contract=off is part of the contract: the reference evaluates every TensorFlow op as a
-// separately rounded fp32 op, so no multiply-add here may be fused into an FMA; divisions are
-// IEEE (hipcc's default correctly-rounded fp32 divide).  No MFMA: the path is elementwise and
-// reduction work, HBM-bound except the dense-crowd matcher (VALU-bound).
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-honor-nans (see build.py).
+// No FMA contraction (each fp32 op rounds separately, like the reference's TF ops) and IEEE
+// division.  -fno-honor-nans changes no rounding; scores and boxes are finite by contract and
+// it lets v_min/v_max be emitted without a canonicalising pre-op on every operand.
 //
 // Reference citations are file:line under the reference tree (bioothod/object_detection).
-#include <hip/hip_runtime.h>
-#include <math.h>
-#include <stdarg.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <stdlib.h>
+#include "odbox_common.h"
 
-#include "odbox.h"
+using namespace odbox;
 
 namespace {
-
-// ------------------------------------------------------------------------------------------
-// error plumbing
-// ------------------------------------------------------------------------------------------
-thread_local char g_err[512] = "";
-
-int fail(int code, const char *fmt, ...)
-{
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof g_err, fmt, ap);
-    va_end(ap);
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                       \
-    do {                                                                                    \
-        hipError_t e_ = (expr);                                                             \
-        if (e_ != hipSuccess) return fail(ODBOX_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
-
-inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
-inline int launch_status(const char *what)
-{
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(ODBOX_EHIP, "launch %s: %s", what, hipGetErrorString(e));
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------
-constexpr int WAVE = 64;
-// ints between per-image atomic counters: returning atomics on one cache line serialise in L2
-// (measured: 64 counters packed in 256 B cap a kernel at ~240 atomics/us chip-wide)
-constexpr uint32_t CNT_STRIDE = 64;
-
-// Blocks are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2), so give each
-// XCD a contiguous run of tiles: neighbouring output tiles then meet in one L2.  Bijective for
-// every grid size.  Affinity only, never correctness.
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblocks)
-{
-    uint32_t xcd = bid & 7u, q = nblocks >> 3, r = nblocks & 7u;
-    uint32_t start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + (bid >> 3);
-}
-
-// x / d and x % d for x*e < d*2^32 with m = floor(2^32 / d): one mulhi and one fix-up.
-__device__ __forceinline__ void divmod_u32(uint32_t x, uint32_t d, uint32_t m, uint32_t &q, uint32_t &r)
-{
-    q = __umulhi(x, m);
-    r = x - q * d;
-    if (r >= d) { ++q; r -= d; }
-}
-
-// fp32 -> uint32 whose unsigned order is the float order (finite inputs; -0 folded into +0).
-__device__ __forceinline__ uint32_t f32_ordered(float s)
-{
-    uint32_t u = __float_as_uint(s + 0.0f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float f32_unordered(uint32_t o)
-{
-    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
-}
-
-// Candidate key  [class:12][~ordered(score):32][anchor:20] : ascending u64 order is
-// (class asc, score desc, anchor asc) = the visiting order of per-class greedy NMS.
-// Final key      [~ordered(score):32][class:12][anchor:20] : ascending order is (score desc,
-// class asc, anchor asc) = tf.math.top_k over the class-ordered concat (bndbox.py:220-229):
-// inside one class equal scores were selected in ascending anchor order.
-__device__ __forceinline__ uint64_t cand_key(uint32_t cls, float score, uint32_t anchor)
-{
-    return ((uint64_t)cls << 52) | ((uint64_t)(~f32_ordered(score)) << 20) | anchor;
-}
-__device__ __forceinline__ uint32_t key_class(uint64_t k) { return (uint32_t)(k >> 52); }
-__device__ __forceinline__ uint32_t key_anchor(uint64_t k) { return (uint32_t)k & 0xfffffu; }
-__device__ __forceinline__ float key_score(uint64_t k) { return f32_unordered(~(uint32_t)(k >> 20)); }
-__device__ __forceinline__ uint64_t cand_to_final(uint64_t k)
-{
-    return ((k >> 20) << 32) | ((k >> 52) << 20) | (k & 0xfffffu);
-}
-__device__ __forceinline__ uint64_t final_to_cand(uint64_t k)
-{
-    return (((k >> 20) & 0xfffu) << 52) | ((k >> 32) << 20) | (k & 0xfffffu);
-}
-// pre-NMS top-k order [~score:32][anchor:20][class:12]: (score desc, anchor asc)
-__device__ __forceinline__ uint64_t cand_to_topk(uint64_t k)
-{
-    return (((k >> 20) & 0xffffffffull) << 32) | ((k & 0xfffffu) << 12) | (k >> 52);
-}
-__device__ __forceinline__ uint64_t topk_to_cand(uint64_t k)
-{
-    return ((k & 0xfffu) << 52) | ((k >> 32) << 20) | ((k >> 12) & 0xfffffu);
-}
-
-// ------------------------------------------------------------------------------------------
-// anchors.py:60-87  tile base anchors over a feature map
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void anchor_tile_kernel(const float4 *__restrict__ base, int A, int fw,
-                                                          float stride, float4 *__restrict__ out,
-                                                          uint32_t total)
-{
-    uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= total) return;
-    uint32_t cell = t / (uint32_t)A, a = t - cell * (uint32_t)A;
-    uint32_t i = cell / (uint32_t)fw, j = cell - i * (uint32_t)fw;
-    float sx = ((float)j + 0.5f) * stride;
-    float sy = ((float)i + 0.5f) * stride;
-    float4 b = base[a];
-    out[t] = make_float4(b.x + sx, b.y + sy, b.z + sx, b.w + sy);
-}
-
-// ------------------------------------------------------------------------------------------
-// bndbox.py:273-297  IoU of one (anchor, GT) pair, GT area precomputed
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float pair_iou(const float4 a, float a_area, const float4 g, float g_area)
-{
-    float ix0 = fmaxf(a.x, g.x);
-    float ix1 = fminf(a.z, g.z);
-    float iy0 = fmaxf(a.y, g.y);
-    float iy1 = fminf(a.w, g.w);
-    float i_area = fmaxf(ix1 - ix0, 0.0f) * fmaxf(iy1 - iy0, 0.0f);
-    float u_area = ((a_area + g_area) - i_area) + 1e-8f;
-    return i_area / u_area;
-}
-
-// ------------------------------------------------------------------------------------------
-// Fused matcher + encoder: anchors.py:116-213 (+ :215-274, :277-299, bndbox.py:254-299).
-//
-// One block = one tile of ME_TILE anchors of one image.
-//   phase 1  thread = anchor: GT boxes of the image staged in LDS (box, area, pad flag) in
-//            chunks of ME_GCHUNK, IoU + strict-> argmax in registers (first max wins).
-//   phase 2  thresholds, out-of-image test, label, offsets; compact outputs stored directly;
-//            5 regression floats and a packed (label, state) word staged in LDS.
-//   phase 3  the two dense outputs of the tile are contiguous in memory ([tile,5] and
-//            [tile,C+1] floats): the block streams them as 16-byte stores over the FLAT element
-//            range (head/tail handled with scalar stores), rebuilding each one-hot element from
-//            the packed word.  This is the HBM-bound part: 4(C+1)+20 of the 4(C+1)+36 bytes.
-// ------------------------------------------------------------------------------------------
-constexpr int ME_TILE = 256;
-constexpr int ME_GCHUNK = 512;
-
-__global__ __launch_bounds__(ME_TILE) void match_encode_kernel(
-    const float4 *__restrict__ anchors, const float4 *__restrict__ gt_boxes,
-    const int32_t *__restrict__ gt_labels, int N, int G, int C, float img_h, float img_w,
-    float neg_thr, float pos_thr, float *__restrict__ out_reg, float *__restrict__ out_lab,
-    int32_t *__restrict__ out_idx, int8_t *__restrict__ out_state, float *__restrict__ out_iou,
-    uint32_t tiles_per_image, uint32_t d_magic)
-{
-    __shared__ float4 s_gt[ME_GCHUNK];
-    __shared__ float2 s_ga[ME_GCHUNK];          // (area, 1.0 if padded row else 0.0)
-    __shared__ float s_reg[ME_TILE * 5];
-    __shared__ uint32_t s_ls[ME_TILE];          // (label + 1) | (state + 1) << 16
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t b = blk / tiles_per_image;
-    const uint32_t n0 = (blk - b * tiles_per_image) * ME_TILE;
-    const uint32_t n = n0 + tid;
-    const bool live = n < (uint32_t)N;
-    const uint32_t tile_n = min((uint32_t)ME_TILE, (uint32_t)N - n0);
-
-    const float4 a = live ? anchors[n] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float a_area = (a.w - a.y) * (a.z - a.x);                       // bndbox.py:285
-
-    // ---- phase 1: argmax_g IoU ------------------------------------------------------------
-    int best = 0;
-    float best_iou = -INFINITY;
-    const float4 *gtb = gt_boxes + (size_t)b * G;
-    for (int g0 = 0; g0 < G; g0 += ME_GCHUNK) {
-        const int cnt = min(ME_GCHUNK, G - g0);
-        if (g0) __syncthreads();
-        for (int g = tid; g < cnt; g += ME_TILE) {
-            float4 gb = gtb[g0 + g];
-            float area = (gb.w - gb.y) * (gb.z - gb.x);                  // bndbox.py:286
-            float gmax = fmaxf(fmaxf(gb.x, gb.y), fmaxf(gb.z, gb.w));    // bndbox.py:295
-            s_gt[g] = gb;
-            s_ga[g] = make_float2(area, gmax < 0.0f ? 1.0f : 0.0f);
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int g = 0; g < cnt; ++g) {
-            float4 gb = s_gt[g];
-            float2 ga = s_ga[g];
-            float v = pair_iou(a, a_area, gb, ga.x);
-            v = ga.y != 0.0f ? -1.0f : v;                                // bndbox.py:297
-            if (v > best_iou) { best_iou = v; best = g0 + g; }           // tf.argmax: first max
-        }
-    }
-
-    // ---- phase 2: states, label, offsets ---------------------------------------------------
-    const bool positive = best_iou >= pos_thr;                            // anchors.py:267
-    bool ignore = ((best_iou > neg_thr) && !positive) || (best_iou < 0.0f);   // :270-272
-    const float xc = (a.x + a.z) / 2.0f;                                  // :178-184
-    const float yc = (a.y + a.w) / 2.0f;
-    ignore = ignore || (xc >= img_w) || (yc >= img_h);
-    const int state = ignore ? -1 : (positive ? 1 : 0);
-    int label = -1;
-    if (live && positive && !ignore && gt_labels) label = gt_labels[(size_t)b * G + best];
-    if (label < 0 || label >= C) label = -1;                              // tf.one_hot: zero row
-
-    const size_t row = (size_t)b * N + n;
-    if (live) {
-        if (out_idx) out_idx[row] = best;
-        if (out_state) out_state[row] = (int8_t)state;
-        if (out_iou) out_iou[row] = best_iou;
-    }
-    if (out_reg) {                                                        // anchors.py:286-297
-        const float4 g = gtb[best];
-        const float aw = a.z - a.x, ah = a.w - a.y;
-        s_reg[tid * 5 + 0] = (((g.x - a.x) / aw) - 0.0f) / 0.2f;
-        s_reg[tid * 5 + 1] = (((g.y - a.y) / ah) - 0.0f) / 0.2f;
-        s_reg[tid * 5 + 2] = (((g.z - a.z) / aw) - 0.0f) / 0.2f;
-        s_reg[tid * 5 + 3] = (((g.w - a.w) / ah) - 0.0f) / 0.2f;
-        s_reg[tid * 5 + 4] = (float)state;
-    }
-    s_ls[tid] = (uint32_t)(label + 1) | ((uint32_t)(state + 1) << 16);
-    __syncthreads();
-
-    // ---- phase 3a: [tile,5] regression rows, flat 16-byte stores ---------------------------
-    if (out_reg) {
-        float *p = out_reg + ((size_t)b * N + n0) * 5;
-        const uint32_t count = tile_n * 5;
-        const uint32_t head = min(count, (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) >> 2);
-        const uint32_t nvec = (count - head) >> 2;
-        if (tid < head) p[tid] = s_reg[tid];
-        for (uint32_t v = tid; v < nvec; v += ME_TILE) {
-            const uint32_t e = head + 4 * v;
-            *reinterpret_cast<float4 *>(p + e) = make_float4(s_reg[e], s_reg[e + 1], s_reg[e + 2], s_reg[e + 3]);
-        }
-        const uint32_t done = head + 4 * nvec;
-        if (tid < count - done) p[done + tid] = s_reg[done + tid];
-    }
-
-    // ---- phase 3b: [tile,C+1] one-hot + state rows, flat 16-byte stores --------------------
-    if (out_lab) {
-        const uint32_t d = (uint32_t)C + 1u;
-        float *p = out_lab + ((size_t)b * N + n0) * d;
-        const uint32_t count = tile_n * d;
-        const uint32_t head = min(count, (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) >> 2);
-        const uint32_t nvec = (count - head) >> 2;
-        auto element = [&](uint32_t ls, uint32_t col) -> float {
-            const uint32_t lab1 = ls & 0xffffu;                      // label + 1, 0 = none
-            const float st = (float)((int)(ls >> 16) - 1);
-            return col == d - 1 ? st : (col + 1 == lab1 ? 1.0f : 0.0f);
-        };
-        if (tid < head) {
-            uint32_t q, r;
-            divmod_u32(tid, d, d_magic, q, r);
-            p[tid] = element(s_ls[q], r);
-        }
-        for (uint32_t v = tid; v < nvec; v += ME_TILE) {
-            const uint32_t e = head + 4 * v;
-            uint32_t q, r;
-            divmod_u32(e, d, d_magic, q, r);
-            uint32_t ls = s_ls[q];
-            float o[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                o[k] = element(ls, r);
-                if (++r == d) {
-                    r = 0;
-                    ++q;
-                    ls = s_ls[min(q, (uint32_t)ME_TILE - 1)];
-                }
-            }
-            *reinterpret_cast<float4 *>(p + e) = make_float4(o[0], o[1], o[2], o[3]);
-        }
-        const uint32_t done = head + 4 * nvec;
-        if (tid < count - done) {
-            uint32_t q, r;
-            divmod_u32(done + tid, d, d_magic, q, r);
-            p[done + tid] = element(s_ls[q], r);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// bndbox.py:254-299  dense [B,N,G] IoU (API parity; the training path never materialises it)
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bbox_overlap_kernel(const float4 *__restrict__ anchors,
-                                                           const float4 *__restrict__ gt, int N, int G,
-                                                           int anchors_batched, float *__restrict__ out,
-                                                           size_t total)
-{
-    size_t t = (size_t)blockIdx.x * 256u + threadIdx.x;
-    if (t >= total) return;
-    size_t bn = t / (size_t)G;
-    uint32_t g = (uint32_t)(t - bn * (size_t)G);
-    size_t b = bn / (size_t)N;
-    size_t n = bn - b * (size_t)N;
-    float4 a = anchors[anchors_batched ? bn : n];
-    float4 gb = gt[b * (size_t)G + g];
-    float a_area = (a.w - a.y) * (a.z - a.x);
-    float g_area = (gb.w - gb.y) * (gb.z - gb.x);
-    float v = pair_iou(a, a_area, gb, g_area);
-    float gmax = fmaxf(fmaxf(gb.x, gb.y), fmaxf(gb.z, gb.w));
-    out[t] = gmax < 0.0f ? -1.0f : v;
-}
-
-// ------------------------------------------------------------------------------------------
-// elementwise box ops
-// ------------------------------------------------------------------------------------------
-// bndbox.py:88-99
-__device__ __forceinline__ float4 regress_one(const float4 a, const float4 r)
-{
-    const float w = a.z - a.x, h = a.w - a.y;
-    return make_float4(a.x + (r.x * 0.2f + 0.0f) * w, a.y + (r.y * 0.2f + 0.0f) * h,
-                       a.z + (r.z * 0.2f + 0.0f) * w, a.w + (r.w * 0.2f + 0.0f) * h);
-}
-// bndbox.py:105-115
-__device__ __forceinline__ float4 clip_one(const float4 v, float hi_x, float hi_y)
-{
-    return make_float4(fminf(fmaxf(v.x, 0.0f), hi_x), fminf(fmaxf(v.y, 0.0f), hi_y),
-                       fminf(fmaxf(v.z, 0.0f), hi_x), fminf(fmaxf(v.w, 0.0f), hi_y));
-}
-
-__global__ __launch_bounds__(256) void regress_kernel(const float4 *__restrict__ boxes, int boxes_batched,
-                                                      const float4 *__restrict__ reg, uint32_t N,
-                                                      float4 *__restrict__ out, size_t total)
-{
-    size_t t = (size_t)blockIdx.x * 256u + threadIdx.x;
-    if (t >= total) return;
-    float4 a = boxes[boxes_batched ? t : t % N];
-    out[t] = regress_one(a, reg[t]);
-}
-
-__global__ __launch_bounds__(256) void clip_kernel(const float4 *__restrict__ boxes, float hi_x, float hi_y,
-                                                   float4 *__restrict__ out, size_t total)
-{
-    size_t t = (size_t)blockIdx.x * 256u + threadIdx.x;
-    if (t >= total) return;
-    out[t] = clip_one(boxes[t], hi_x, hi_y);
-}
-
-__global__ __launch_bounds__(256) void scale_kernel(const float4 *__restrict__ boxes, float fx, float fy,
-                                                    int divide, float4 *__restrict__ out, size_t total)
-{
-    size_t t = (size_t)blockIdx.x * 256u + threadIdx.x;
-    if (t >= total) return;
-    float4 v = boxes[t];
-    out[t] = divide ? make_float4(v.x / fx, v.y / fy, v.z / fx, v.w / fy)
-                    : make_float4(v.x * fx, v.y * fy, v.z * fx, v.w * fy);
-}
-
-// anchors.py:286-297
-__global__ __launch_bounds__(256) void transform_kernel(const float4 *__restrict__ anchors, int anchors_batched,
-                                                        const float4 *__restrict__ gt, uint32_t N,
-                                                        float4 *__restrict__ out, size_t total)
-{
-    size_t t = (size_t)blockIdx.x * 256u + threadIdx.x;
-    if (t >= total) return;
-    float4 a = anchors[anchors_batched ? t : t % N];
-    float4 g = gt[t];
-    const float aw = a.z - a.x, ah = a.w - a.y;
-    out[t] = make_float4((((g.x - a.x) / aw) - 0.0f) / 0.2f, (((g.y - a.y) / ah) - 0.0f) / 0.2f,
-                         (((g.z - a.z) / aw) - 0.0f) / 0.2f, (((g.w - a.w) / ah) - 0.0f) / 0.2f);
-}
 
 // ------------------------------------------------------------------------------------------
 // decode + NMS, kernel 1: stream the [B,N,C] scores once (the HBM-bound kernel).
@@ -713,26 +348,100 @@ __device__ __forceinline__ uint64_t wave_sort64(uint64_t key, uint32_t lane)
     return key;
 }
 
+// 64 * KPL keys sorted across the wave in registers, element e = lane * KPL + slot (the same
+// flip network; stages whose distance is below KPL stay inside a lane, the others exchange
+// registers with the partner lane).  MERGE_ONLY: the input is one bitonic sequence and only
+// the last merge (half-cleaners 32*KPL .. 1) runs.
+template <int KPL, bool MERGE_ONLY = false>
+__device__ __forceinline__ void wave_sort_regs(uint64_t (&k)[KPL], uint32_t lane)
+{
+    constexpr uint32_t P = WAVE * KPL;
+    auto cmpswap = [](uint64_t &lo, uint64_t &hi) {
+        const uint64_t x = lo, y = hi;
+        lo = x < y ? x : y;
+        hi = x < y ? y : x;
+    };
+    auto keep = [](uint64_t mine, uint64_t other, bool lower) {
+        const bool take_other = lower ? (other < mine) : (other > mine);
+        return take_other ? other : mine;
+    };
+    constexpr int LOGP = 6 + (KPL == 1 ? 0 : KPL == 2 ? 1 : KPL == 4 ? 2 : 3);
+#pragma unroll
+    for (int lk = MERGE_ONLY ? LOGP : 1; lk <= LOGP; ++lk) {
+        const uint32_t kk = 1u << lk;
+        if (!MERGE_ONLY) {                       // flip stage: partner e ^ (kk - 1)
+            if (kk <= (uint32_t)KPL) {
+#pragma unroll
+                for (uint32_t s0 = 0; s0 < (uint32_t)KPL; ++s0)
+                    if ((s0 ^ (kk - 1)) > s0) cmpswap(k[s0], k[s0 ^ (kk - 1)]);
+            } else {
+                const uint32_t lp = lane ^ (kk / KPL - 1);
+                const bool lower = (lane & (kk / (2 * KPL))) == 0;
+                uint64_t other[KPL];
+#pragma unroll
+                for (uint32_t s0 = 0; s0 < (uint32_t)KPL; ++s0) other[s0] = __shfl(k[KPL - 1 - s0], (int)lp);
+#pragma unroll
+                for (uint32_t s0 = 0; s0 < (uint32_t)KPL; ++s0) k[s0] = keep(k[s0], other[s0], lower);
+            }
+        }
+#pragma unroll
+        for (int lj = MERGE_ONLY ? lk - 1 : lk - 2; lj >= 0; --lj) {           // half-cleaners: partner e ^ j
+            const uint32_t j = 1u << lj;
+            if (j < (uint32_t)KPL) {
+#pragma unroll
+                for (uint32_t s0 = 0; s0 < (uint32_t)KPL; ++s0)
+                    if ((s0 & j) == 0) cmpswap(k[s0], k[s0 | j]);
+            } else {
+                const uint32_t lp = lane ^ (j / KPL);
+                const bool lower = (lane & (j / KPL)) == 0;
+#pragma unroll
+                for (uint32_t s0 = 0; s0 < (uint32_t)KPL; ++s0) k[s0] = keep(k[s0], __shfl(k[s0], (int)lp), lower);
+            }
+        }
+    }
+}
+
+// sort n <= 64 * KPL keys of `src` (any memory) into the wave's LDS array `dst`
+template <int KPL>
+__device__ __forceinline__ void wave_sort_to_lds(const uint64_t *src, uint32_t n, uint64_t *dst, uint32_t lane)
+{
+    uint64_t k[KPL];
+#pragma unroll
+    for (uint32_t s0 = 0; s0 < (uint32_t)KPL; ++s0) {
+        const uint32_t e = lane * KPL + s0;
+        k[s0] = e < n ? src[e] : ~0ull;
+    }
+    wave_sort_regs<KPL>(k, lane);
+#pragma unroll
+    for (uint32_t s0 = 0; s0 < (uint32_t)KPL; ++s0) {
+        const uint32_t e = lane * KPL + s0;
+        if (e < n) dst[e] = k[s0];
+    }
+}
+
 constexpr int SORT_THREADS = 1024;
 constexpr uint32_t SORT_LDS_CAP = 16384;   // keys a block sorts in LDS (128 KiB); more: in global memory
 constexpr uint32_t NMS_SEG_LDS = 512;      // keys one NMS wave sorts by itself; bigger segments: block sort
 
 // kernel 2: counting sort of one image's candidate keys by class (LDS histogram -> scan ->
-// scatter).  Writes the class segment starts and flags the image for the block sort when one
-// class holds more keys than an NMS wave sorts on its own.
+// scatter); writes the class segment starts.  When one class holds more keys than an NMS wave
+// sorts on its own (NMS_SEG_LDS) the block also sorts the whole list -- it is grouped by class
+// already, so a full key sort puts every segment in visiting order -- and flags the image.
 constexpr int PART_THREADS = 512;
 
 __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
     const int *__restrict__ cand_count, const uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out,
     uint32_t cand_stride, int C, int *__restrict__ seg_start, int *__restrict__ big_flag)
 {
-    extern __shared__ int s_hist[];      // [C] counts -> cursors, then [PART_THREADS] scan scratch
-    int *s_scan = s_hist + C;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_part[];
+    int *s_hist = reinterpret_cast<int *>(s_part);       // [C] counts -> cursors
+    int *s_scan = s_hist + C;                            // [PART_THREADS] scan scratch, [PART_THREADS] = flag
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const uint32_t M = min((uint32_t)cand_count[b * CNT_STRIDE], cand_stride);
     const uint64_t *in = keys_in + (size_t)b * cand_stride;
     uint64_t *out = keys_out + (size_t)b * cand_stride;
     for (int c = tid; c < C; c += PART_THREADS) s_hist[c] = 0;
+    if (tid == 0) s_scan[PART_THREADS] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < M; i += PART_THREADS) atomicAdd(&s_hist[key_class(in[i])], 1);
     __syncthreads();
@@ -742,6 +451,7 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
     int local = 0, biggest = 0;
     for (int c = c0; c < c1; ++c) { local += s_hist[c]; biggest = max(biggest, s_hist[c]); }
     s_scan[tid] = local;
+    if (biggest > (int)NMS_SEG_LDS) s_scan[PART_THREADS] = 1;
     __syncthreads();
     for (int off = 1; off < PART_THREADS; off <<= 1) {
         const int v = tid >= (uint32_t)off ? s_scan[tid - off] : 0;
@@ -758,19 +468,30 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
         run += cnt;
     }
     if (tid == 0) seg[C] = (int)M;
-    if (biggest > (int)NMS_SEG_LDS) atomicOr(big_flag + b, 1);
+    const bool big = s_scan[PART_THREADS] != 0;
     __syncthreads();
     for (uint32_t i = tid; i < M; i += PART_THREADS) {
         const uint64_t k = in[i];
         out[atomicAdd(&s_hist[key_class(k)], 1)] = k;
     }
+    if (!big) return;                                    // block-uniform
+    if (tid == 0) big_flag[b] = 1;
+    __syncthreads();                                     // scatter visible to the whole block
+    if (M <= SORT_LDS_CAP) {
+        uint64_t *s_keys = reinterpret_cast<uint64_t *>(s_part);
+        for (uint32_t i = tid; i < M; i += PART_THREADS) s_keys[i] = out[i];
+        __syncthreads();
+        sort_u64<true>(s_keys, M, tid, PART_THREADS);
+        for (uint32_t i = tid; i < M; i += PART_THREADS) out[i] = s_keys[i];
+    } else {
+        sort_u64<true>(out, M, tid, PART_THREADS);
+    }
 }
 
-// kernel 2b: block sort of a whole image's candidate list.
-//   mode 0 (pre-NMS top-k requested): keep the best pre_nms_topk keys by (score desc, anchor
-//          asc), sort them (class asc, score desc, anchor asc), write the segment starts.
-//   mode 1: only images flagged by the partition kernel (a class segment too long for one
-//          wave); the list is already grouped by class, sorting it fully orders every segment.
+// kernel 2b (only when a pre-NMS top-k is requested, instead of kernel 2): block sort of a whole
+// image's candidate list: keep the best pre_nms_topk keys by (score desc, anchor asc), sort
+// them (class asc, score desc, anchor asc), write the segment starts.  (mode is always 0 now;
+// mode 1 = "only flagged images" is kept for experiments.)
 __global__ __launch_bounds__(SORT_THREADS) void cand_sort_kernel(
     int *__restrict__ cand_count, uint64_t *__restrict__ cand_keys, uint32_t cand_stride, int C,
     int pre_nms_topk, int mode, int *__restrict__ seg_start, int *__restrict__ big_flag)
@@ -827,15 +548,32 @@ __device__ __forceinline__ float4 candidate_box(const float4 *__restrict__ ancho
     return v;
 }
 
-// TF NonMaxSuppressionV3 IoU on min/max-normalised boxes with precomputed areas
-// (third-party kernel semantics; call site bndbox.py:170-175)
-__device__ __forceinline__ float nms_iou(const float4 p, float pa, const float4 q, float qa)
+// TF NonMaxSuppressionV3 suppression test on min/max-normalised boxes with precomputed areas
+// (third-party kernel semantics; call site bndbox.py:170-175):
+//     area_p <= 0 or area_q <= 0  ->  IoU = 0;  suppress iff  fl(inter / fl(fl(pa + qa) - inter)) > thr.
+// The division is only evaluated where it can matter: with u the rounded union, inter >
+// fl(thr_hi * u) already implies fl(inter / u) > thr and inter < fl(thr_lo * u) implies the
+// opposite (thr_hi/lo = thr * (1 +- 2^-20), far outside the 2^-23 rounding of either side), so
+// only lanes inside that band (practically none) take the exact IEEE division.  The result is
+// bit-identical to always dividing.
+struct NmsThr {
+    float thr, lo, hi;
+};
+
+__device__ __forceinline__ bool nms_suppresses(const float4 p, float pa, float qx0, float qy0, float qx1,
+                                               float qy1, float qa, const NmsThr t)
 {
-    if (pa <= 0.0f || qa <= 0.0f) return 0.0f;
-    const float ih = fmaxf(fminf(p.w, q.w) - fmaxf(p.y, q.y), 0.0f);
-    const float iw = fmaxf(fminf(p.z, q.z) - fmaxf(p.x, q.x), 0.0f);
+    const float ih = fmaxf(fminf(p.w, qy1) - fmaxf(p.y, qy0), 0.0f);
+    const float iw = fmaxf(fminf(p.z, qx1) - fmaxf(p.x, qx0), 0.0f);
     const float inter = ih * iw;
-    return inter / ((pa + qa) - inter);
+    const float uni = (pa + qa) - inter;
+    const bool valid = (pa > 0.0f) && (qa > 0.0f);
+    const bool above = inter > t.hi * uni;
+    const bool below = inter < t.lo * uni;
+    bool res = valid && above;
+    if (__ballot(valid && !above && !below) != 0ull)        // wave-uniform, almost never taken
+        res = valid && (above || (!below && (inter / uni > t.thr)));
+    return res;
 }
 
 // value of lane j (wave-uniform j) through an SGPR (v_readlane_b32), no LDS crossbar trip
@@ -846,15 +584,18 @@ __device__ __forceinline__ float bcast_lane(float v, int j)
 
 // kernel 3: greedy NMS, one wave per (image, class) segment.  The wave first puts its segment
 // in visiting order (score desc, anchor asc): <= 64 keys in registers, <= NMS_SEG_LDS keys in
-// its own LDS, longer segments were sorted by cand_sort_kernel.  The kept list (<= max_ret
-// boxes) lives in LDS; candidates are taken 64 at a time: tested against the kept list, then
-// resolved inside the chunk with ballots (the lowest live lane is kept and suppresses the lanes
-// above it).  Stops at max_ret kept (bndbox.py:172).
+// its own LDS, longer segments were sorted by cand_sort_kernel.  Candidates are taken 64 at a
+// time (one per lane): tested against the kept list, then resolved inside the chunk with
+// ballots (the lowest live lane is kept and suppresses the lanes above it).  The first 128
+// kept boxes live in REGISTERS, kept box k in lane k & 63 of register set k >> 6, and are
+// broadcast with v_readlane (an SGPR operand, no LDS latency in the serial chain); only a kept
+// list longer than that (max_ret > 128) continues in LDS.  Stops at max_ret kept (bndbox.py:172).
 constexpr int NMS_WAVES = 4;
+constexpr int NMS_REG_KEPT = 128;
 
 __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
     const float4 *__restrict__ anchors, const float4 *__restrict__ rb, int N, int C, int do_clip,
-    float hi_x, float hi_y, float iou_thr, int max_ret, const uint64_t *__restrict__ cand_keys,
+    float hi_x, float hi_y, NmsThr thr, int max_ret, const uint64_t *__restrict__ cand_keys,
     uint32_t cand_stride, const int *__restrict__ seg_start, const int *__restrict__ big_flag,
     int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys, uint32_t fin_stride,
     uint32_t total_segments, int waves_per_block, uint32_t per_wave_bytes, uint32_t dbg)
@@ -872,7 +613,7 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
     const uint32_t m = (uint32_t)(end - start);
 
     unsigned char *mine = s_raw + (size_t)wave * per_wave_bytes;
-    float4 *s_box = reinterpret_cast<float4 *>(mine);
+    float4 *s_box = reinterpret_cast<float4 *>(mine);                     // kept boxes >= NMS_REG_KEPT
     uint64_t *s_key = reinterpret_cast<uint64_t *>(mine + (size_t)max_ret * 16);
     float *s_area = reinterpret_cast<float *>(mine + (size_t)max_ret * 24);
     uint64_t *s_sort = reinterpret_cast<uint64_t *>(mine + (((size_t)max_ret * 28 + 15) & ~(size_t)15));
@@ -885,13 +626,20 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
         if (m <= WAVE) {
             reg_key = wave_sort64(lane < m ? keys[lane] : ~0ull, lane);
         } else {                                    // m <= NMS_SEG_LDS by the partition kernel's flag
-            for (uint32_t i = lane; i < m; i += WAVE) s_sort[i] = keys[i];
+            if (m <= 2 * WAVE)
+                wave_sort_to_lds<2>(keys, m, s_sort, lane);
+            else if (m <= 4 * WAVE)
+                wave_sort_to_lds<4>(keys, m, s_sort, lane);
+            else
+                wave_sort_to_lds<8>(keys, m, s_sort, lane);
             sort_sync<false>();
-            sort_u64<false>(s_sort, m, lane, WAVE);
             sorted = s_sort;
         }
     }
 
+    // kept boxes 0..127: lane k & 63 of set A (k < 64) or set B
+    float ax0 = 0.f, ay0 = 0.f, ax1 = 0.f, ay1 = 0.f, aa = 0.f;
+    float bx0 = 0.f, by0 = 0.f, bx1 = 0.f, by1 = 0.f, ba = 0.f;
     int kept = 0;
     for (uint32_t base = 0; base < m && kept < max_ret && !(dbg & 2u); base += WAVE) {
         const uint32_t i = base + lane;
@@ -905,23 +653,45 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
             nb = make_float4(fminf(v.x, v.z), fminf(v.y, v.w), fmaxf(v.x, v.z), fmaxf(v.y, v.w));
             area = (nb.w - nb.y) * (nb.z - nb.x);
         }
+        // (1) against the kept list as it stands at the start of the chunk
         bool alive = valid;
-        for (int k = 0; k < kept; ++k) {
-            if (alive && nms_iou(nb, area, s_box[k], s_area[k]) > iou_thr) alive = false;
-            if (__ballot(alive) == 0ull) break;
+        const int kA = min(kept, WAVE), kB = min(kept, NMS_REG_KEPT);
+        for (int k = 0; k < kA; ++k)
+            if (nms_suppresses(nb, area, bcast_lane(ax0, k), bcast_lane(ay0, k), bcast_lane(ax1, k),
+                               bcast_lane(ay1, k), bcast_lane(aa, k), thr))
+                alive = false;
+        for (int k = WAVE; k < kB; ++k)
+            if (nms_suppresses(nb, area, bcast_lane(bx0, k - WAVE), bcast_lane(by0, k - WAVE),
+                               bcast_lane(bx1, k - WAVE), bcast_lane(by1, k - WAVE), bcast_lane(ba, k - WAVE), thr))
+                alive = false;
+        for (int k = NMS_REG_KEPT; k < kept; ++k) {
+            const float4 q = s_box[k];
+            if (nms_suppresses(nb, area, q.x, q.y, q.z, q.w, s_area[k], thr)) alive = false;
         }
+        // (2) inside the chunk: the lowest live lane is kept and suppresses the lanes above it
         uint64_t mask = __ballot(alive);
         while (mask != 0ull && kept < max_ret) {
             const int j = __ffsll((unsigned long long)mask) - 1;
-            const float4 jb = make_float4(bcast_lane(nb.x, j), bcast_lane(nb.y, j), bcast_lane(nb.z, j), bcast_lane(nb.w, j));
-            const float ja = bcast_lane(area, j);
+            const float jx0 = bcast_lane(nb.x, j), jy0 = bcast_lane(nb.y, j), jx1 = bcast_lane(nb.z, j),
+                        jy1 = bcast_lane(nb.w, j), ja = bcast_lane(area, j);
+            const bool slot = (int)lane == (kept & 63);
+            if (kept < WAVE) {
+                ax0 = slot ? jx0 : ax0; ay0 = slot ? jy0 : ay0; ax1 = slot ? jx1 : ax1;
+                ay1 = slot ? jy1 : ay1; aa = slot ? ja : aa;
+            } else if (kept < NMS_REG_KEPT) {
+                bx0 = slot ? jx0 : bx0; by0 = slot ? jy0 : by0; bx1 = slot ? jx1 : bx1;
+                by1 = slot ? jy1 : by1; ba = slot ? ja : ba;
+            }
             if ((int)lane == j) {
-                s_box[kept] = nb;
-                s_area[kept] = area;
+                if (kept >= NMS_REG_KEPT) {
+                    s_box[kept] = nb;
+                    s_area[kept] = area;
+                }
                 s_key[kept] = key;
             }
             ++kept;
-            if (alive && (int)lane > j && nms_iou(nb, area, jb, ja) > iou_thr) alive = false;
+            const bool hit = nms_suppresses(nb, area, jx0, jy0, jx1, jy1, ja, thr);
+            if ((int)lane > j && hit) alive = false;
             mask = __ballot(alive) & ~((2ull << j) - 1ull);
         }
         sort_sync<false>();
@@ -939,7 +709,12 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
 
 // kernel 4: per image, order the kept detections like tf.math.top_k over the class-ordered
 // concat (bndbox.py:220-229), emit the first max_ret and zero-pad the rest (:233-244).
-constexpr int FIN_THREADS = 256;
+// Fast path (max_ret <= 128, list fits LDS): only the 128 smallest keys are ever needed, so
+// every wave sorts 128-key chunks in registers, then chunk pairs are merged keeping the lower
+// half (min(A[e], B[127-e]) is bitonic and holds the 128 smallest of both; one register merge
+// sorts it) -- log2(chunks) rounds instead of a full sort of the list.
+constexpr int FIN_THREADS = 1024;
+constexpr uint32_t FIN_CHUNK = 128;
 
 __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
     const float4 *__restrict__ anchors, const float4 *__restrict__ rb, int N, int do_clip, float hi_x,
@@ -948,17 +723,12 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
     int32_t *__restrict__ out_labels, int32_t *__restrict__ out_keep, int32_t *__restrict__ out_count)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
-    const uint32_t b = blockIdx.x;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
     uint64_t *gk = fin_keys + (size_t)b * fin_stride;
     const uint32_t n = min((uint32_t)fin_count[b * CNT_STRIDE], fin_stride);
     const uint32_t keep = min(n, (uint32_t)max_ret);
-    auto run = [&](auto k, bool staged) {
-        if (staged) {
-            for (uint32_t i = threadIdx.x; i < n; i += FIN_THREADS) k[i] = gk[i];
-            __syncthreads();
-        }
-        sort_u64<true>(k, n, threadIdx.x, FIN_THREADS);
-        for (uint32_t r = threadIdx.x; r < (uint32_t)max_ret; r += FIN_THREADS) {
+    auto emit = [&](auto k) {
+        for (uint32_t r = tid; r < (uint32_t)max_ret; r += FIN_THREADS) {
             const size_t o = (size_t)b * max_ret + r;
             if (r < keep) {
                 const uint64_t ck = final_to_cand(k[r]);
@@ -975,11 +745,50 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
             }
         }
     };
-    if (n <= SORT_LDS_CAP)
-        run(s_keys, true);
-    else
-        run(gk, false);
-    if (out_count && threadIdx.x == 0) out_count[b] = (int32_t)keep;
+    if (out_count && tid == 0) out_count[b] = (int32_t)keep;
+
+    if ((uint32_t)max_ret <= FIN_CHUNK && n <= SORT_LDS_CAP) {
+        const uint32_t nchunks = (n + FIN_CHUNK - 1) / FIN_CHUNK;
+        const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = FIN_THREADS / WAVE;
+        for (uint32_t i = tid; i < nchunks * FIN_CHUNK; i += FIN_THREADS) s_keys[i] = i < n ? gk[i] : ~0ull;
+        __syncthreads();
+        for (uint32_t c = wave; c < nchunks; c += nwaves) {
+            uint64_t k[2];
+            uint64_t *ch = s_keys + c * FIN_CHUNK;
+            k[0] = ch[lane * 2];
+            k[1] = ch[lane * 2 + 1];
+            wave_sort_regs<2>(k, lane);
+            ch[lane * 2] = k[0];
+            ch[lane * 2 + 1] = k[1];
+        }
+        __syncthreads();
+        for (uint32_t stride = 1; stride < nchunks; stride <<= 1) {
+            for (uint32_t c = wave * 2 * stride; c + stride < nchunks; c += nwaves * 2 * stride) {
+                uint64_t *lo = s_keys + c * FIN_CHUNK;
+                const uint64_t *hi = s_keys + (c + stride) * FIN_CHUNK;
+                uint64_t k[2];
+#pragma unroll
+                for (uint32_t s0 = 0; s0 < 2; ++s0) {
+                    const uint32_t e = lane * 2 + s0;
+                    const uint64_t x = lo[e], y = hi[FIN_CHUNK - 1 - e];
+                    k[s0] = x < y ? x : y;
+                }
+                wave_sort_regs<2, true>(k, lane);
+                lo[lane * 2] = k[0];
+                lo[lane * 2 + 1] = k[1];
+            }
+            __syncthreads();
+        }
+        emit(s_keys);
+    } else if (n <= SORT_LDS_CAP) {
+        for (uint32_t i = tid; i < n; i += FIN_THREADS) s_keys[i] = gk[i];
+        __syncthreads();
+        sort_u64<true>(s_keys, n, tid, FIN_THREADS);
+        emit(s_keys);
+    } else {
+        sort_u64<true>(gk, n, tid, FIN_THREADS);
+        emit(gk);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1149,130 +958,7 @@ int launch_scan(const float *scores, int B, int N, int C, const ScanGeom &g, flo
 
 }  // namespace
 
-// ==========================================================================================
-// C-ABI
-// ==========================================================================================
 extern "C" {
-
-int odbox_version(void) { return ODBOX_VERSION; }
-const char *odbox_last_error(void) { return g_err; }
-
-int odbox_anchor_tile(const float *base, int A, int fh, int fw, float stride, float *out, void *stream)
-{
-    if (A < 1 || fh < 0 || fw < 0) return fail(ODBOX_EINVAL, "odbox_anchor_tile: bad shape A=%d fh=%d fw=%d", A, fh, fw);
-    if (fh == 0 || fw == 0) return 0;
-    if (!base || !out) return fail(ODBOX_EINVAL, "odbox_anchor_tile: NULL pointer");
-    if (!aligned16(base) || !aligned16(out)) return fail(ODBOX_EINVAL, "odbox_anchor_tile: pointers must be 16-byte aligned");
-    const uint64_t total = (uint64_t)fh * fw * A;
-    if (total == 0) return 0;
-    if (total > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_anchor_tile: too many anchors");
-    hipLaunchKernelGGL(anchor_tile_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4 *)base, A, fw, stride, (float4 *)out, (uint32_t)total);
-    return launch_status("anchor_tile");
-}
-
-int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B, int N,
-                       int G, int C, float img_h, float img_w, float neg_thr, float pos_thr,
-                       float *out_regression, float *out_labels, int32_t *out_match_idx, int8_t *out_state,
-                       float *out_max_iou, void *stream)
-{
-    if (B < 0 || N < 0 || G < 1 || C < 1 || C > ODBOX_MAX_CLASSES)
-        return fail(ODBOX_EINVAL, "odbox_match_encode: bad shape B=%d N=%d G=%d C=%d (need G>=1, 1<=C<=%d)", B, N, G, C,
-                    ODBOX_MAX_CLASSES);
-    if (B == 0 || N == 0) return 0;
-    if (!anchors || !gt_boxes) return fail(ODBOX_EINVAL, "odbox_match_encode: NULL input");
-    if (out_labels && !gt_labels) return fail(ODBOX_EINVAL, "odbox_match_encode: out_labels needs gt_labels");
-    if (!aligned16(anchors) || !aligned16(gt_boxes))
-        return fail(ODBOX_EINVAL, "odbox_match_encode: anchors / gt_boxes must be 16-byte aligned");
-    if (B == 0 || N == 0) return 0;
-    const uint64_t tiles = ((uint64_t)N + ME_TILE - 1) / ME_TILE;
-    const uint64_t blocks = tiles * (uint64_t)B;
-    if (blocks > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_match_encode: grid too large");
-    const uint32_t d = (uint32_t)C + 1u;
-    const uint32_t magic = d == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / d);
-    hipLaunchKernelGGL(match_encode_kernel, dim3((uint32_t)blocks), dim3(ME_TILE), 0, (hipStream_t)stream,
-                       (const float4 *)anchors, (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w,
-                       neg_thr, pos_thr, out_regression, out_labels, out_match_idx, out_state, out_max_iou,
-                       (uint32_t)tiles, magic);
-    return launch_status("match_encode");
-}
-
-int odbox_bbox_overlap(const float *anchors, const float *gt_boxes, int B, int N, int G, int anchors_batched,
-                       float *out_iou, void *stream)
-{
-    if (B < 0 || N < 0 || G < 0) return fail(ODBOX_EINVAL, "odbox_bbox_overlap: bad shape");
-    if ((size_t)B * N * G == 0) return 0;
-    if (!anchors || !gt_boxes || !out_iou) return fail(ODBOX_EINVAL, "odbox_bbox_overlap: NULL pointer");
-    if (!aligned16(anchors) || !aligned16(gt_boxes))
-        return fail(ODBOX_EINVAL, "odbox_bbox_overlap: inputs must be 16-byte aligned");
-    const size_t total = (size_t)B * N * G;
-    if (total == 0) return 0;
-    const size_t blocks = (total + 255) / 256;
-    if (blocks > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_bbox_overlap: grid too large");
-    hipLaunchKernelGGL(bbox_overlap_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const float4 *)anchors, (const float4 *)gt_boxes, N, G, anchors_batched, out_iou, total);
-    return launch_status("bbox_overlap");
-}
-
-static int elementwise_check(const char *name, const void *a, const void *b, const void *c, size_t total,
-                             size_t &blocks)
-{
-    blocks = 0;
-    if (total == 0) return 0;
-    if (!a || !b || !c) return fail(ODBOX_EINVAL, "%s: NULL pointer", name);
-    if (!aligned16(a) || !aligned16(b) || !aligned16(c)) return fail(ODBOX_EINVAL, "%s: pointers must be 16-byte aligned", name);
-    blocks = (total + 255) / 256;
-    if (blocks > 0x7fffffffull) return fail(ODBOX_EINVAL, "%s: grid too large", name);
-    return 0;
-}
-
-int odbox_bbox_transform(const float *anchors, int anchors_batched, const float *gt_boxes, int B, int N,
-                         float *out, void *stream)
-{
-    if (B < 0 || N < 0) return fail(ODBOX_EINVAL, "odbox_bbox_transform: bad shape");
-    const size_t total = (size_t)B * N;
-    size_t blocks;
-    if (int rc = elementwise_check("odbox_bbox_transform", anchors, gt_boxes, out, total, blocks)) return rc;
-    if (total == 0) return 0;
-    hipLaunchKernelGGL(transform_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const float4 *)anchors, anchors_batched, (const float4 *)gt_boxes, (uint32_t)N,
-                       (float4 *)out, total);
-    return launch_status("bbox_transform");
-}
-
-int odbox_regress_boxes(const float *boxes, int boxes_batched, const float *regressors, int B, int N,
-                        float *out, void *stream)
-{
-    if (B < 0 || N < 0) return fail(ODBOX_EINVAL, "odbox_regress_boxes: bad shape");
-    const size_t total = (size_t)B * N;
-    size_t blocks;
-    if (int rc = elementwise_check("odbox_regress_boxes", boxes, regressors, out, total, blocks)) return rc;
-    if (total == 0) return 0;
-    hipLaunchKernelGGL(regress_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const float4 *)boxes, boxes_batched, (const float4 *)regressors, (uint32_t)N,
-                       (float4 *)out, total);
-    return launch_status("regress_boxes");
-}
-
-int odbox_clip_boxes(const float *boxes, size_t n, float img_h, float img_w, float *out, void *stream)
-{
-    size_t blocks;
-    if (int rc = elementwise_check("odbox_clip_boxes", boxes, boxes, out, n, blocks)) return rc;
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(clip_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const float4 *)boxes, img_w - 1.0f, img_h - 1.0f, (float4 *)out, n);
-    return launch_status("clip_boxes");
-}
-
-int odbox_scale_boxes(const float *boxes, size_t n, float fx, float fy, int divide, float *out, void *stream)
-{
-    size_t blocks;
-    if (int rc = elementwise_check("odbox_scale_boxes", boxes, boxes, out, n, blocks)) return rc;
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(scale_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const float4 *)boxes, fx, fy, divide, (float4 *)out, n);
-    return launch_status("scale_boxes");
-}
 
 size_t odbox_decode_nms_workspace(int B, int N, int C, int max_ret, int pre_nms_topk)
 {
@@ -1335,13 +1021,12 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
         if (int r2 = launch_status("cand_sort")) return r2;
         nms_keys = keys_a;
     } else {
-        const size_t part_lds = (size_t)(C + PART_THREADS) * sizeof(int);
+        size_t part_lds = (size_t)(C + PART_THREADS + 1) * sizeof(int);
+        if (part_lds < sort_lds) part_lds = sort_lds;       // the block may have to sort the whole list
+        if (int r2 = allow_lds(cand_partition_kernel, part_lds)) return r2;
         hipLaunchKernelGGL(cand_partition_kernel, dim3(B), dim3(PART_THREADS), part_lds, st, cand_count, keys_a, keys_b,
                            L.cand_stride, C, seg_start, big_flag);
         if (int r2 = launch_status("cand_partition")) return r2;
-        hipLaunchKernelGGL(cand_sort_kernel, dim3(B), dim3(SORT_THREADS), sort_lds, st, cand_count, keys_b,
-                           L.cand_stride, C, 0, 1, seg_start, big_flag);
-        if (int r2 = launch_status("cand_sort")) return r2;
         nms_keys = keys_b;
     }
 
@@ -1349,16 +1034,17 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
     const size_t per_wave = align_up((size_t)max_ret * 28, 16) + (size_t)NMS_SEG_LDS * 8;
     const int waves = per_wave * NMS_WAVES <= 64 * 1024 ? NMS_WAVES : 1;
     const uint64_t segs = (uint64_t)B * C;
+    const NmsThr nms_thr = {iou_thr, iou_thr * (1.0f - 0x1p-20f), iou_thr * (1.0f + 0x1p-20f)};
     if (int r3 = allow_lds(nms_kernel, per_wave * waves)) return r3;
     hipLaunchKernelGGL(nms_kernel, dim3((uint32_t)((segs + waves - 1) / waves)), dim3(waves * WAVE), per_wave * waves,
                        st, (const float4 *)anchors, (const float4 *)regress_or_boxes, N, C, do_clip, hi_x, hi_y,
-                       iou_thr, max_ret, nms_keys, L.cand_stride, seg_start, big_flag, fin_count, fin_keys,
+                       nms_thr, max_ret, nms_keys, L.cand_stride, seg_start, big_flag, fin_count, fin_keys,
                        L.fin_stride, (uint32_t)segs, waves, (uint32_t)per_wave,
                        (uint32_t)(getenv("ODBOX_NMS_DBG") ? atoi(getenv("ODBOX_NMS_DBG")) : 0));
     if (int r3 = launch_status("nms")) return r3;
 
     // kernel 4: final order, top max_ret, zero padding
-    const size_t fin_lds = (size_t)(L.fin_stride < SORT_LDS_CAP ? L.fin_stride : SORT_LDS_CAP) * 8;
+    const size_t fin_lds = align_up((size_t)(L.fin_stride < SORT_LDS_CAP ? L.fin_stride : SORT_LDS_CAP), FIN_CHUNK) * 8;
     if (int r4 = allow_lds(finalize_kernel, fin_lds)) return r4;
     hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(FIN_THREADS), fin_lds, st, (const float4 *)anchors,
                        (const float4 *)regress_or_boxes, N, do_clip, hi_x, hi_y, max_ret, fin_count, fin_keys,

@@ -1,0 +1,404 @@
+// odbox_train.hip -- training-side kernels (anchor tiling, fused IoU matcher + target encoder,
+// dense IoU, elementwise box ops) + their C-ABI (include/odbox.h), gfx950 / wave64.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).  -ffp-contract=off is
+// part of the contract: the reference evaluates every TensorFlow op as a separately rounded
+// fp32 op, so no multiply-add here may be fused into an FMA; divisions are IEEE (hipcc's
+// default correctly-rounded fp32 divide).  No MFMA: the path is elementwise and reduction work,
+// HBM-bound except the dense-crowd matcher (VALU-bound).
+//
+// Reference citations are file:line under the reference tree (bioothod/object_detection).
+#include "odbox_common.h"
+
+namespace odbox {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+const char *last_error() { return g_err; }
+
+}  // namespace odbox
+
+using namespace odbox;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// anchors.py:60-87  tile base anchors over a feature map
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void anchor_tile_kernel(const float4 *__restrict__ base, int A, int fw,
+                                                          float stride, float4 *__restrict__ out,
+                                                          uint32_t total)
+{
+    uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= total) return;
+    uint32_t cell = t / (uint32_t)A, a = t - cell * (uint32_t)A;
+    uint32_t i = cell / (uint32_t)fw, j = cell - i * (uint32_t)fw;
+    float sx = ((float)j + 0.5f) * stride;
+    float sy = ((float)i + 0.5f) * stride;
+    float4 b = base[a];
+    out[t] = make_float4(b.x + sx, b.y + sy, b.z + sx, b.w + sy);
+}
+
+// ------------------------------------------------------------------------------------------
+// bndbox.py:273-297  IoU of one (anchor, GT) pair, GT area precomputed
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pair_iou(const float4 a, float a_area, const float4 g, float g_area)
+{
+    float ix0 = fmaxf(a.x, g.x);
+    float ix1 = fminf(a.z, g.z);
+    float iy0 = fmaxf(a.y, g.y);
+    float iy1 = fminf(a.w, g.w);
+    float i_area = fmaxf(ix1 - ix0, 0.0f) * fmaxf(iy1 - iy0, 0.0f);
+    float u_area = ((a_area + g_area) - i_area) + 1e-8f;
+    return i_area / u_area;
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused matcher + encoder: anchors.py:116-213 (+ :215-274, :277-299, bndbox.py:254-299).
+//
+// One block = one tile of ME_TILE anchors of one image.
+//   phase 1  thread = anchor: GT boxes of the image staged in LDS (box, area, pad flag) in
+//            chunks of ME_GCHUNK, IoU + strict-> argmax in registers (first max wins).
+//   phase 2  thresholds, out-of-image test, label, offsets; compact outputs stored directly;
+//            5 regression floats and a packed (label, state) word staged in LDS.
+//   phase 3  the two dense outputs of the tile are contiguous in memory ([tile,5] and
+//            [tile,C+1] floats): the block streams them as 16-byte stores over the FLAT element
+//            range (head/tail handled with scalar stores), rebuilding each one-hot element from
+//            the packed word.  This is the HBM-bound part: 4(C+1)+20 of the 4(C+1)+36 bytes.
+// ------------------------------------------------------------------------------------------
+constexpr int ME_TILE = 256;
+constexpr int ME_GCHUNK = 512;
+
+__global__ __launch_bounds__(ME_TILE) void match_encode_kernel(
+    const float4 *__restrict__ anchors, const float4 *__restrict__ gt_boxes,
+    const int32_t *__restrict__ gt_labels, int N, int G, int C, float img_h, float img_w,
+    float neg_thr, float pos_thr, float *__restrict__ out_reg, float *__restrict__ out_lab,
+    int32_t *__restrict__ out_idx, int8_t *__restrict__ out_state, float *__restrict__ out_iou,
+    uint32_t tiles_per_image, uint32_t d_magic)
+{
+    __shared__ float4 s_gt[ME_GCHUNK];
+    __shared__ float2 s_ga[ME_GCHUNK];          // (area, 1.0 if padded row else 0.0)
+    __shared__ float s_reg[ME_TILE * 5];
+    __shared__ uint32_t s_ls[ME_TILE];          // (label + 1) | (state + 1) << 16
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t b = blk / tiles_per_image;
+    const uint32_t n0 = (blk - b * tiles_per_image) * ME_TILE;
+    const uint32_t n = n0 + tid;
+    const bool live = n < (uint32_t)N;
+    const uint32_t tile_n = min((uint32_t)ME_TILE, (uint32_t)N - n0);
+
+    const float4 a = live ? anchors[n] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float a_area = (a.w - a.y) * (a.z - a.x);                       // bndbox.py:285
+
+    // ---- phase 1: argmax_g IoU ------------------------------------------------------------
+    int best = 0;
+    float best_iou = -INFINITY;
+    const float4 *gtb = gt_boxes + (size_t)b * G;
+    for (int g0 = 0; g0 < G; g0 += ME_GCHUNK) {
+        const int cnt = min(ME_GCHUNK, G - g0);
+        if (g0) __syncthreads();
+        for (int g = tid; g < cnt; g += ME_TILE) {
+            float4 gb = gtb[g0 + g];
+            float area = (gb.w - gb.y) * (gb.z - gb.x);                  // bndbox.py:286
+            float gmax = fmaxf(fmaxf(gb.x, gb.y), fmaxf(gb.z, gb.w));    // bndbox.py:295
+            s_gt[g] = gb;
+            s_ga[g] = make_float2(area, gmax < 0.0f ? 1.0f : 0.0f);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int g = 0; g < cnt; ++g) {
+            float4 gb = s_gt[g];
+            float2 ga = s_ga[g];
+            float v = pair_iou(a, a_area, gb, ga.x);
+            v = ga.y != 0.0f ? -1.0f : v;                                // bndbox.py:297
+            if (v > best_iou) { best_iou = v; best = g0 + g; }           // tf.argmax: first max
+        }
+    }
+
+    // ---- phase 2: states, label, offsets ---------------------------------------------------
+    const bool positive = best_iou >= pos_thr;                            // anchors.py:267
+    bool ignore = ((best_iou > neg_thr) && !positive) || (best_iou < 0.0f);   // :270-272
+    const float xc = (a.x + a.z) / 2.0f;                                  // :178-184
+    const float yc = (a.y + a.w) / 2.0f;
+    ignore = ignore || (xc >= img_w) || (yc >= img_h);
+    const int state = ignore ? -1 : (positive ? 1 : 0);
+    int label = -1;
+    if (live && positive && !ignore && gt_labels) label = gt_labels[(size_t)b * G + best];
+    if (label < 0 || label >= C) label = -1;                              // tf.one_hot: zero row
+
+    const size_t row = (size_t)b * N + n;
+    if (live) {
+        if (out_idx) out_idx[row] = best;
+        if (out_state) out_state[row] = (int8_t)state;
+        if (out_iou) out_iou[row] = best_iou;
+    }
+    if (out_reg) {                                                        // anchors.py:286-297
+        const float4 g = gtb[best];
+        const float aw = a.z - a.x, ah = a.w - a.y;
+        s_reg[tid * 5 + 0] = (((g.x - a.x) / aw) - 0.0f) / 0.2f;
+        s_reg[tid * 5 + 1] = (((g.y - a.y) / ah) - 0.0f) / 0.2f;
+        s_reg[tid * 5 + 2] = (((g.z - a.z) / aw) - 0.0f) / 0.2f;
+        s_reg[tid * 5 + 3] = (((g.w - a.w) / ah) - 0.0f) / 0.2f;
+        s_reg[tid * 5 + 4] = (float)state;
+    }
+    s_ls[tid] = (uint32_t)(label + 1) | ((uint32_t)(state + 1) << 16);
+    __syncthreads();
+
+    // ---- phase 3a: [tile,5] regression rows, flat 16-byte stores ---------------------------
+    if (out_reg) {
+        float *p = out_reg + ((size_t)b * N + n0) * 5;
+        const uint32_t count = tile_n * 5;
+        const uint32_t head = min(count, (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) >> 2);
+        const uint32_t nvec = (count - head) >> 2;
+        if (tid < head) p[tid] = s_reg[tid];
+        for (uint32_t v = tid; v < nvec; v += ME_TILE) {
+            const uint32_t e = head + 4 * v;
+            *reinterpret_cast<float4 *>(p + e) = make_float4(s_reg[e], s_reg[e + 1], s_reg[e + 2], s_reg[e + 3]);
+        }
+        const uint32_t done = head + 4 * nvec;
+        if (tid < count - done) p[done + tid] = s_reg[done + tid];
+    }
+
+    // ---- phase 3b: [tile,C+1] one-hot + state rows, flat 16-byte stores --------------------
+    if (out_lab) {
+        const uint32_t d = (uint32_t)C + 1u;
+        float *p = out_lab + ((size_t)b * N + n0) * d;
+        const uint32_t count = tile_n * d;
+        const uint32_t head = min(count, (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) >> 2);
+        const uint32_t nvec = (count - head) >> 2;
+        auto element = [&](uint32_t ls, uint32_t col) -> float {
+            const uint32_t lab1 = ls & 0xffffu;                      // label + 1, 0 = none
+            const float st = (float)((int)(ls >> 16) - 1);
+            return col == d - 1 ? st : (col + 1 == lab1 ? 1.0f : 0.0f);
+        };
+        if (tid < head) {
+            uint32_t q, r;
+            divmod_u32(tid, d, d_magic, q, r);
+            p[tid] = element(s_ls[q], r);
+        }
+        for (uint32_t v = tid; v < nvec; v += ME_TILE) {
+            const uint32_t e = head + 4 * v;
+            uint32_t q, r;
+            divmod_u32(e, d, d_magic, q, r);
+            uint32_t ls = s_ls[q];
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o[k] = element(ls, r);
+                if (++r == d) {
+                    r = 0;
+                    ++q;
+                    ls = s_ls[min(q, (uint32_t)ME_TILE - 1)];
+                }
+            }
+            *reinterpret_cast<float4 *>(p + e) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        const uint32_t done = head + 4 * nvec;
+        if (tid < count - done) {
+            uint32_t q, r;
+            divmod_u32(done + tid, d, d_magic, q, r);
+            p[done + tid] = element(s_ls[q], r);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// bndbox.py:254-299  dense [B,N,G] IoU (API parity; the training path never materialises it)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bbox_overlap_kernel(const float4 *__restrict__ anchors,
+                                                           const float4 *__restrict__ gt, int N, int G,
+                                                           int anchors_batched, float *__restrict__ out,
+                                                           size_t total)
+{
+    size_t t = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (t >= total) return;
+    size_t bn = t / (size_t)G;
+    uint32_t g = (uint32_t)(t - bn * (size_t)G);
+    size_t b = bn / (size_t)N;
+    size_t n = bn - b * (size_t)N;
+    float4 a = anchors[anchors_batched ? bn : n];
+    float4 gb = gt[b * (size_t)G + g];
+    float a_area = (a.w - a.y) * (a.z - a.x);
+    float g_area = (gb.w - gb.y) * (gb.z - gb.x);
+    float v = pair_iou(a, a_area, gb, g_area);
+    float gmax = fmaxf(fmaxf(gb.x, gb.y), fmaxf(gb.z, gb.w));
+    out[t] = gmax < 0.0f ? -1.0f : v;
+}
+
+__global__ __launch_bounds__(256) void regress_kernel(const float4 *__restrict__ boxes, int boxes_batched,
+                                                      const float4 *__restrict__ reg, uint32_t N,
+                                                      float4 *__restrict__ out, size_t total)
+{
+    size_t t = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (t >= total) return;
+    float4 a = boxes[boxes_batched ? t : t % N];
+    out[t] = regress_one(a, reg[t]);
+}
+
+__global__ __launch_bounds__(256) void clip_kernel(const float4 *__restrict__ boxes, float hi_x, float hi_y,
+                                                   float4 *__restrict__ out, size_t total)
+{
+    size_t t = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (t >= total) return;
+    out[t] = clip_one(boxes[t], hi_x, hi_y);
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(const float4 *__restrict__ boxes, float fx, float fy,
+                                                    int divide, float4 *__restrict__ out, size_t total)
+{
+    size_t t = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (t >= total) return;
+    float4 v = boxes[t];
+    out[t] = divide ? make_float4(v.x / fx, v.y / fy, v.z / fx, v.w / fy)
+                    : make_float4(v.x * fx, v.y * fy, v.z * fx, v.w * fy);
+}
+
+// anchors.py:286-297
+__global__ __launch_bounds__(256) void transform_kernel(const float4 *__restrict__ anchors, int anchors_batched,
+                                                        const float4 *__restrict__ gt, uint32_t N,
+                                                        float4 *__restrict__ out, size_t total)
+{
+    size_t t = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (t >= total) return;
+    float4 a = anchors[anchors_batched ? t : t % N];
+    float4 g = gt[t];
+    const float aw = a.z - a.x, ah = a.w - a.y;
+    out[t] = make_float4((((g.x - a.x) / aw) - 0.0f) / 0.2f, (((g.y - a.y) / ah) - 0.0f) / 0.2f,
+                         (((g.z - a.z) / aw) - 0.0f) / 0.2f, (((g.w - a.w) / ah) - 0.0f) / 0.2f);
+}
+
+}  // namespace
+
+extern "C" {
+
+int odbox_version(void) { return ODBOX_VERSION; }
+const char *odbox_last_error(void) { return odbox::last_error(); }
+
+int odbox_anchor_tile(const float *base, int A, int fh, int fw, float stride, float *out, void *stream)
+{
+    if (A < 1 || fh < 0 || fw < 0) return fail(ODBOX_EINVAL, "odbox_anchor_tile: bad shape A=%d fh=%d fw=%d", A, fh, fw);
+    if (fh == 0 || fw == 0) return 0;
+    if (!base || !out) return fail(ODBOX_EINVAL, "odbox_anchor_tile: NULL pointer");
+    if (!aligned16(base) || !aligned16(out)) return fail(ODBOX_EINVAL, "odbox_anchor_tile: pointers must be 16-byte aligned");
+    const uint64_t total = (uint64_t)fh * fw * A;
+    if (total == 0) return 0;
+    if (total > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_anchor_tile: too many anchors");
+    hipLaunchKernelGGL(anchor_tile_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)base, A, fw, stride, (float4 *)out, (uint32_t)total);
+    return launch_status("anchor_tile");
+}
+
+int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B, int N,
+                       int G, int C, float img_h, float img_w, float neg_thr, float pos_thr,
+                       float *out_regression, float *out_labels, int32_t *out_match_idx, int8_t *out_state,
+                       float *out_max_iou, void *stream)
+{
+    if (B < 0 || N < 0 || G < 1 || C < 1 || C > ODBOX_MAX_CLASSES)
+        return fail(ODBOX_EINVAL, "odbox_match_encode: bad shape B=%d N=%d G=%d C=%d (need G>=1, 1<=C<=%d)", B, N, G, C,
+                    ODBOX_MAX_CLASSES);
+    if (B == 0 || N == 0) return 0;
+    if (!anchors || !gt_boxes) return fail(ODBOX_EINVAL, "odbox_match_encode: NULL input");
+    if (out_labels && !gt_labels) return fail(ODBOX_EINVAL, "odbox_match_encode: out_labels needs gt_labels");
+    if (!aligned16(anchors) || !aligned16(gt_boxes))
+        return fail(ODBOX_EINVAL, "odbox_match_encode: anchors / gt_boxes must be 16-byte aligned");
+    if (B == 0 || N == 0) return 0;
+    const uint64_t tiles = ((uint64_t)N + ME_TILE - 1) / ME_TILE;
+    const uint64_t blocks = tiles * (uint64_t)B;
+    if (blocks > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_match_encode: grid too large");
+    const uint32_t d = (uint32_t)C + 1u;
+    const uint32_t magic = d == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / d);
+    hipLaunchKernelGGL(match_encode_kernel, dim3((uint32_t)blocks), dim3(ME_TILE), 0, (hipStream_t)stream,
+                       (const float4 *)anchors, (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w,
+                       neg_thr, pos_thr, out_regression, out_labels, out_match_idx, out_state, out_max_iou,
+                       (uint32_t)tiles, magic);
+    return launch_status("match_encode");
+}
+
+int odbox_bbox_overlap(const float *anchors, const float *gt_boxes, int B, int N, int G, int anchors_batched,
+                       float *out_iou, void *stream)
+{
+    if (B < 0 || N < 0 || G < 0) return fail(ODBOX_EINVAL, "odbox_bbox_overlap: bad shape");
+    if ((size_t)B * N * G == 0) return 0;
+    if (!anchors || !gt_boxes || !out_iou) return fail(ODBOX_EINVAL, "odbox_bbox_overlap: NULL pointer");
+    if (!aligned16(anchors) || !aligned16(gt_boxes))
+        return fail(ODBOX_EINVAL, "odbox_bbox_overlap: inputs must be 16-byte aligned");
+    const size_t total = (size_t)B * N * G;
+    if (total == 0) return 0;
+    const size_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_bbox_overlap: grid too large");
+    hipLaunchKernelGGL(bbox_overlap_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)anchors, (const float4 *)gt_boxes, N, G, anchors_batched, out_iou, total);
+    return launch_status("bbox_overlap");
+}
+
+static int elementwise_check(const char *name, const void *a, const void *b, const void *c, size_t total,
+                             size_t &blocks)
+{
+    blocks = 0;
+    if (total == 0) return 0;
+    if (!a || !b || !c) return fail(ODBOX_EINVAL, "%s: NULL pointer", name);
+    if (!aligned16(a) || !aligned16(b) || !aligned16(c)) return fail(ODBOX_EINVAL, "%s: pointers must be 16-byte aligned", name);
+    blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffull) return fail(ODBOX_EINVAL, "%s: grid too large", name);
+    return 0;
+}
+
+int odbox_bbox_transform(const float *anchors, int anchors_batched, const float *gt_boxes, int B, int N,
+                         float *out, void *stream)
+{
+    if (B < 0 || N < 0) return fail(ODBOX_EINVAL, "odbox_bbox_transform: bad shape");
+    const size_t total = (size_t)B * N;
+    size_t blocks;
+    if (int rc = elementwise_check("odbox_bbox_transform", anchors, gt_boxes, out, total, blocks)) return rc;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(transform_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)anchors, anchors_batched, (const float4 *)gt_boxes, (uint32_t)N,
+                       (float4 *)out, total);
+    return launch_status("bbox_transform");
+}
+
+int odbox_regress_boxes(const float *boxes, int boxes_batched, const float *regressors, int B, int N,
+                        float *out, void *stream)
+{
+    if (B < 0 || N < 0) return fail(ODBOX_EINVAL, "odbox_regress_boxes: bad shape");
+    const size_t total = (size_t)B * N;
+    size_t blocks;
+    if (int rc = elementwise_check("odbox_regress_boxes", boxes, regressors, out, total, blocks)) return rc;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(regress_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)boxes, boxes_batched, (const float4 *)regressors, (uint32_t)N,
+                       (float4 *)out, total);
+    return launch_status("regress_boxes");
+}
+
+int odbox_clip_boxes(const float *boxes, size_t n, float img_h, float img_w, float *out, void *stream)
+{
+    size_t blocks;
+    if (int rc = elementwise_check("odbox_clip_boxes", boxes, boxes, out, n, blocks)) return rc;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(clip_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)boxes, img_w - 1.0f, img_h - 1.0f, (float4 *)out, n);
+    return launch_status("clip_boxes");
+}
+
+int odbox_scale_boxes(const float *boxes, size_t n, float fx, float fy, int divide, float *out, void *stream)
+{
+    size_t blocks;
+    if (int rc = elementwise_check("odbox_scale_boxes", boxes, boxes, out, n, blocks)) return rc;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(scale_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)boxes, fx, fy, divide, (float4 *)out, n);
+    return launch_status("scale_boxes");
+}
+
+}  // extern "C"
