@@ -612,11 +612,14 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
     if (end <= start) return;
     const uint32_t m = (uint32_t)(end - start);
 
+    // per-wave LDS: [sorted segment keys: NMS_SEG_LDS][kept keys: max_ret][kept boxes and areas
+    // beyond the register-resident NMS_REG_KEPT: extra * 20 bytes]
     unsigned char *mine = s_raw + (size_t)wave * per_wave_bytes;
-    float4 *s_box = reinterpret_cast<float4 *>(mine);                     // kept boxes >= NMS_REG_KEPT
-    uint64_t *s_key = reinterpret_cast<uint64_t *>(mine + (size_t)max_ret * 16);
-    float *s_area = reinterpret_cast<float *>(mine + (size_t)max_ret * 24);
-    uint64_t *s_sort = reinterpret_cast<uint64_t *>(mine + (((size_t)max_ret * 28 + 15) & ~(size_t)15));
+    const int extra = max_ret > NMS_REG_KEPT ? max_ret - NMS_REG_KEPT : 0;
+    uint64_t *s_sort = reinterpret_cast<uint64_t *>(mine);
+    uint64_t *s_key = s_sort + NMS_SEG_LDS;
+    float4 *s_box = reinterpret_cast<float4 *>(s_key + ((max_ret + 1) & ~1)) - NMS_REG_KEPT;   // indexed by kept
+    float *s_area = reinterpret_cast<float *>(s_box + NMS_REG_KEPT + extra) - NMS_REG_KEPT;
 
     const uint64_t *keys = cand_keys + (size_t)b * cand_stride + start;
     const bool presorted = big_flag[b] != 0;
@@ -1031,7 +1034,8 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
     }
 
     // kernel 3: per-(image, class) greedy NMS
-    const size_t per_wave = align_up((size_t)max_ret * 28, 16) + (size_t)NMS_SEG_LDS * 8;
+    const size_t nms_extra = max_ret > NMS_REG_KEPT ? (size_t)(max_ret - NMS_REG_KEPT) : 0;
+    const size_t per_wave = align_up((size_t)NMS_SEG_LDS * 8 + (size_t)((max_ret + 1) & ~1) * 8 + nms_extra * 20, 16);
     const int waves = per_wave * NMS_WAVES <= 64 * 1024 ? NMS_WAVES : 1;
     const uint64_t segs = (uint64_t)B * C;
     const NmsThr nms_thr = {iou_thr, iou_thr * (1.0f - 0x1p-20f), iou_thr * (1.0f + 0x1p-20f)};
