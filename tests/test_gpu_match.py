@@ -145,6 +145,31 @@ def test_cfg3_large_properties():
     assert torch.equal(labels[..., :80].argmax(-1)[pos], want_cls[pos])
 
 
+def test_degenerate_boxes_and_gt_culling_stay_exact():
+    """The kernel leaves GT rows that cannot touch a wave's anchors out of its loop and folds them
+    back in as "first zero row" / "first padded row"; that shortcut is only taken for non-negative
+    areas.  Inverted (negative-area) and zero-area anchors / GT rows, far-away GT rows, leading
+    padded rows and all-zero-IoU images must still give the oracle's argmax bit for bit."""
+    rng = np.random.default_rng(77)
+    anchors = O.generate_anchors(256)
+    N = anchors.shape[0]
+    inv = anchors.copy()
+    inv[::7] = inv[::7][:, [2, 1, 0, 3]]             # x0 > x1: negative width
+    inv[5::11, 3] = inv[5::11, 1]                    # zero height
+    G = 40
+    gts = [workloads.gt_boxes(rng, 256, G - 8, 5, pad_to=G) for _ in range(4)]
+    gt = np.stack([g[0] for g in gts])
+    lab = np.stack([g[1] for g in gts])
+    gt[0, [0, 1]] = -1                               # padding first: argmax must still be row 0 when all IoU <= -1 .. 0
+    lab[0, [0, 1]] = -1
+    gt[1, 3] = gt[1, 3][[2, 1, 0, 3]]                # inverted GT row
+    gt[1, 4, 2] = gt[1, 4, 0]                        # zero-width GT row
+    gt[2, :G - 8] = [1000, 1000, 1010, 1010]         # every valid row far outside the image: all IoU 0
+    gt[3, :G - 8, :] += 4000                         # all rows far away -> everything culled
+    for a in (anchors, inv):
+        check_targets(a, (256, 256), gt, lab, 5)
+
+
 def test_compute_gt_annotations_and_overlap_and_transform():
     rng = np.random.default_rng(5)
     anchors = O.tile_anchors(O.base_anchors(32, (1, 2, .5)), 9, 9, 8)

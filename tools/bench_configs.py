@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""All five BASELINE.json configurations on ONE MI355X (per-GPU shares for the multi-GPU ones):
+HIP-event time per launch, images/s, fraction of the roofline that bounds it.  Documentation
+aid (BASELINE.md / DESIGN.md tables); the driver's bench is bench.py.
+
+    python tools/bench_configs.py [--cfg 1 2 3 4 5] [--iters 20]
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from object_detection_amd import _lib, anchors as A, bndbox as BB, workloads  # noqa: E402
+
+HBM = 8000.0
+VALU_OPS = 39.3e12          # 256 CU x 64 lanes x 2.4 GHz, non-packed, no FMA
+
+
+def event_time(fn, iters, warm=5):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def grid(cfg):
+    c = workloads.CONFIGS[cfg]
+    if c['grid'] == 'yolo':
+        parts = [A.AnchorGenerator(s, [1], st)((c['S'] // st, c['S'] // st, 3)) for s, st in ((32, 8), (64, 16), (128, 32))]
+        return torch.cat(parts, 0)
+    return A.generate_anchors(A.AnchorsConfig(), c['S'])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cfg', type=int, nargs='*', default=[1, 2, 3, 4, 5])
+    ap.add_argument('--iters', type=int, default=20)
+    args = ap.parse_args()
+    lib = _lib.load()
+    dev = _lib.require_gpu()
+    st = _lib.stream_ptr()
+    rows = []
+    for cfg in args.cfg:
+        c = workloads.CONFIGS[cfg]
+        anchors = grid(cfg)
+        N = anchors.shape[0]
+        if cfg == 5:
+            B = 64
+            reg, sc = workloads.nms_inputs(N, C=c['C'], batch=B, p3p4_anchors=9 * (64 * 64 + 32 * 32))
+            reg, sc = torch.as_tensor(reg).to(dev), torch.as_tensor(sc).to(dev)
+            t = event_time(lambda: BB.decode_and_nms(anchors, reg, sc, (c['S'], c['S'])), args.iters)
+            byts = B * workloads.nms_bytes_per_image(N, c['C'])
+            rows.append(dict(cfg=cfg, B=B, N=N, us=t * 1e6, img_s=B / t, GBs=byts / t / 1e9, frac_hbm=byts / t / 1e9 / HBM))
+            continue
+        B = {1: 8, 2: 64, 3: 32, 4: 128}[cfg]
+        gt, lab = workloads.match_inputs(cfg, batch=B)
+        gt, lab = torch.as_tensor(gt).to(dev), torch.as_tensor(lab).to(dev)
+        G, C = gt.shape[1], c['C']
+        reg = torch.empty((B, N, 5), device=dev)
+        out = torch.empty((B, N, C + 1), device=dev)
+
+        def step():
+            rc = lib.odbox_match_encode(anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C, float(c['S']),
+                                        float(c['S']), 0.4, 0.5, reg.data_ptr(), out.data_ptr(), None, None, None, st)
+            assert rc == 0
+        t = event_time(step, args.iters)
+        byts = B * workloads.match_bytes_per_image(N, G, C)
+        row = dict(cfg=cfg, B=B, N=N, G=G, C=C, us=t * 1e6, img_s=B / t, GBs=byts / t / 1e9, frac_hbm=byts / t / 1e9 / HBM)
+        if cfg == 4:
+            ops = 16.0 * N * G * B
+            row['Tops'] = ops / t / 1e12
+            row['frac_valu_nonpacked'] = ops / t / VALU_OPS
+        rows.append(row)
+    for r in rows:
+        print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}))
+
+
+if __name__ == '__main__':
+    main()
