@@ -576,6 +576,31 @@ __device__ __forceinline__ bool nms_suppresses(const float4 p, float pa, float q
     return res;
 }
 
+// branch-free form for unrolled loops: accumulates "certainly suppresses" into hit and "inside the
+// rounding band" into band; the caller resolves band lanes with nms_suppresses_exact
+__device__ __forceinline__ void nms_test(const float4 p, float pa, float qx0, float qy0, float qx1, float qy1,
+                                         float qa, const NmsThr t, bool &hit, bool &band)
+{
+    const float ih = fmaxf(fminf(p.w, qy1) - fmaxf(p.y, qy0), 0.0f);
+    const float iw = fmaxf(fminf(p.z, qx1) - fmaxf(p.x, qx0), 0.0f);
+    const float inter = ih * iw;
+    const float uni = (pa + qa) - inter;
+    const bool valid = (pa > 0.0f) && (qa > 0.0f);
+    const bool above = inter > t.hi * uni;
+    const bool below = inter < t.lo * uni;
+    hit = hit || (valid && above);
+    band = band || (valid && !above && !below);
+}
+__device__ __forceinline__ bool nms_suppresses_exact(const float4 p, float pa, float qx0, float qy0, float qx1,
+                                                     float qy1, float qa, const NmsThr t)
+{
+    if (pa <= 0.0f || qa <= 0.0f) return false;
+    const float ih = fmaxf(fminf(p.w, qy1) - fmaxf(p.y, qy0), 0.0f);
+    const float iw = fmaxf(fminf(p.z, qx1) - fmaxf(p.x, qx0), 0.0f);
+    const float inter = ih * iw;
+    return inter / ((pa + qa) - inter) > t.thr;
+}
+
 // value of lane j (wave-uniform j) through an SGPR (v_readlane_b32), no LDS crossbar trip
 __device__ __forceinline__ float bcast_lane(float v, int j)
 {
@@ -659,14 +684,39 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
         // (1) against the kept list as it stands at the start of the chunk
         bool alive = valid;
         const int kA = min(kept, WAVE), kB = min(kept, NMS_REG_KEPT);
-        for (int k = 0; k < kA; ++k)
-            if (nms_suppresses(nb, area, bcast_lane(ax0, k), bcast_lane(ay0, k), bcast_lane(ax1, k),
-                               bcast_lane(ay1, k), bcast_lane(aa, k), thr))
-                alive = false;
-        for (int k = WAVE; k < kB; ++k)
-            if (nms_suppresses(nb, area, bcast_lane(bx0, k - WAVE), bcast_lane(by0, k - WAVE),
-                               bcast_lane(bx1, k - WAVE), bcast_lane(by1, k - WAVE), bcast_lane(ba, k - WAVE), thr))
-                alive = false;
+        // four kept boxes per iteration: independent chains hide the readlane / compare latency
+        // of the serial form (one segment of 245 candidates: 30 us -> see profiles/README.md)
+        {
+            bool hit = false;
+            auto group4 = [&](const float rx0, const float ry0, const float rx1, const float ry1, const float ra,
+                              int k) {
+                bool band = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    nms_test(nb, area, bcast_lane(rx0, k + u), bcast_lane(ry0, k + u), bcast_lane(rx1, k + u),
+                             bcast_lane(ry1, k + u), bcast_lane(ra, k + u), thr, hit, band);
+                if (__ballot(band && !hit) != 0ull) {       // wave-uniform, practically never
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (nms_suppresses_exact(nb, area, bcast_lane(rx0, k + u), bcast_lane(ry0, k + u),
+                                                 bcast_lane(rx1, k + u), bcast_lane(ry1, k + u), bcast_lane(ra, k + u), thr))
+                            hit = true;
+                }
+            };
+            int k = 0;
+            for (; k + 4 <= kA; k += 4) group4(ax0, ay0, ax1, ay1, aa, k);
+            for (; k < kA; ++k)
+                if (nms_suppresses(nb, area, bcast_lane(ax0, k), bcast_lane(ay0, k), bcast_lane(ax1, k),
+                                   bcast_lane(ay1, k), bcast_lane(aa, k), thr))
+                    hit = true;
+            k = WAVE;
+            for (; k + 4 <= kB; k += 4) group4(bx0, by0, bx1, by1, ba, k - WAVE);
+            for (; k < kB; ++k)
+                if (nms_suppresses(nb, area, bcast_lane(bx0, k - WAVE), bcast_lane(by0, k - WAVE),
+                                   bcast_lane(bx1, k - WAVE), bcast_lane(by1, k - WAVE), bcast_lane(ba, k - WAVE), thr))
+                    hit = true;
+            if (hit) alive = false;
+        }
         for (int k = NMS_REG_KEPT; k < kept; ++k) {
             const float4 q = s_box[k];
             if (nms_suppresses(nb, area, q.x, q.y, q.z, q.w, s_area[k], thr)) alive = false;
