@@ -57,6 +57,34 @@ int odbox_match_encode(const float *anchors /*[N,4]*/, const float *gt_boxes /*[
                        int32_t *out_match_idx /*[B,N]*/, int8_t *out_state /*[B,N]*/,
                        float *out_max_iou /*[B,N]*/, void *stream);
 
+/* Fused matcher + loss, the consumer of the targets: metric.py:97-123 (ModelMetric.__call__) with
+ * focal_loss (metric.py:9-38: clip to [1e-6, 1-1e-6], alpha_t, pow(1-pt, gamma), log) and
+ * tf.keras.losses.Huber(delta, reduction=SUM) evaluated straight from the match, so neither
+ * [B,N,C+1] nor [B,N,5] is ever materialised.
+ * out_loss[4] = { dist_loss, class_loss, npos, 0 }: both losses divided by npos (the number of
+ * foreground anchors) when npos != 0, exactly like metric.py:108-123.
+ * grad_boxes [B,N,4] / grad_scores [B,N,C] (both or neither): gradients of the UNNORMALISED sums
+ * w.r.t. pred_boxes / pred_scores (zero for ignored anchors, background boxes and clipped
+ * scores); divide by npos to get the gradients of the returned losses.
+ * pred_scores are probabilities (the reference calls focal_loss with from_logits=False). */
+size_t odbox_match_loss_workspace(int B, int N);
+int odbox_match_loss(const float *anchors /*[N,4]*/, const float *gt_boxes /*[B,G,4]*/,
+                     const int32_t *gt_labels /*[B,G]*/, int B, int N, int G, int C,
+                     float img_h, float img_w, float neg_thr, float pos_thr,
+                     const float *pred_boxes /*[B,N,4]*/, const float *pred_scores /*[B,N,C]*/,
+                     float gamma, float alpha, float huber_delta, float *out_loss /*[4]*/,
+                     float *grad_boxes /*[B,N,4] or NULL*/, float *grad_scores /*[B,N,C] or NULL*/,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* metric.py:9-38 focal_loss(y_true, y_pred, gamma, alpha, from_logits=False, reduction='sum') on
+ * dense targets (y_true == 1 marks the positive class): out[1] = sum over all n elements
+ * (out has room for 4 floats: out[0], out[2], out[3] are written as 0).  grad [n] or NULL:
+ * d sum / d y_pred.  Used for the whole-image head (metric.py:132-134). */
+size_t odbox_focal_loss_workspace(size_t n);
+int odbox_focal_loss(const float *y_true /*[n]*/, const float *y_pred /*[n]*/, size_t n, float gamma, float alpha,
+                     float *out /*[4]*/, float *grad /*[n] or NULL*/, void *workspace, size_t workspace_bytes,
+                     void *stream);
+
 /* bndbox.py:254-299 bbox_overlap: dense [B,N,G] IoU, -1 for padded GT rows.
  * anchors_batched != 0: anchors is [B,N,4]; else [N,4] shared by every image. */
 int odbox_bbox_overlap(const float *anchors, const float *gt_boxes /*[B,G,4]*/, int B, int N, int G,

@@ -77,28 +77,30 @@ __device__ __forceinline__ float pair_iou(const float4 a, float a_area, const fl
 constexpr int ME_TILE = 256;
 constexpr int ME_GCHUNK = 512;
 
-__global__ __launch_bounds__(ME_TILE) void match_encode_kernel(
-    const float4 *__restrict__ anchors, const float4 *__restrict__ gt_boxes,
-    const int32_t *__restrict__ gt_labels, int N, int G, int C, float img_h, float img_w,
-    float neg_thr, float pos_thr, float *__restrict__ out_reg, float *__restrict__ out_lab,
-    int32_t *__restrict__ out_idx, int8_t *__restrict__ out_state, float *__restrict__ out_iou,
-    uint32_t tiles_per_image, uint32_t d_magic)
+// Phases 1 and 2 of the matcher for the calling thread's anchor n0 + threadIdx.x of image b:
+// anchors.py:215-274 (argmax IoU, thresholds), :178-184 (out-of-image), :187-194 (label).
+// Shared by match_encode_kernel and match_loss_kernel; must be called by all ME_TILE threads.
+struct TileMatch {
+    float4 a;          // the anchor
+    float best_iou;    // max_g IoU (tf.reduce_max)
+    int best;          // argmax_g IoU (tf.argmax: first max)
+    int state;         // -1 ignore / 0 background / 1 foreground
+    int label;         // class of the matched GT if foreground and in [0, C), else -1
+    bool live;         // n < N
+};
+
+__device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ anchors,
+                                                const float4 *__restrict__ gt_boxes,
+                                                const int32_t *__restrict__ gt_labels, uint32_t b, uint32_t n0, int N,
+                                                int G, int C, float img_h, float img_w, float neg_thr, float pos_thr)
 {
     __shared__ float4 s_gt[ME_GCHUNK];
     __shared__ float2 s_ga[ME_GCHUNK];          // (area, 1.0 if padded row else 0.0)
     __shared__ uint16_t s_list[ME_TILE / WAVE][ME_GCHUNK];   // per wave: GT rows it must evaluate
-    __shared__ float s_reg[ME_TILE * 5];
-    __shared__ uint32_t s_ls[ME_TILE];          // (label + 1) | (state + 1) << 16
-
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
-    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t b = blk / tiles_per_image;
-    const uint32_t n0 = (blk - b * tiles_per_image) * ME_TILE;
     const uint32_t n = n0 + tid;
     const bool live = n < (uint32_t)N;
-    const uint32_t tile_n = min((uint32_t)ME_TILE, (uint32_t)N - n0);
-
     const float4 a = live ? anchors[n] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float a_area = (a.w - a.y) * (a.z - a.x);                       // bndbox.py:285
 
@@ -188,6 +190,39 @@ __global__ __launch_bounds__(ME_TILE) void match_encode_kernel(
     int label = -1;
     if (live && positive && !ignore && gt_labels) label = gt_labels[(size_t)b * G + best];
     if (label < 0 || label >= C) label = -1;                              // tf.one_hot: zero row
+    TileMatch r;
+    r.a = a;
+    r.best_iou = best_iou;
+    r.best = best;
+    r.state = state;
+    r.label = label;
+    r.live = live;
+    return r;
+}
+
+__global__ __launch_bounds__(ME_TILE) void match_encode_kernel(
+    const float4 *__restrict__ anchors, const float4 *__restrict__ gt_boxes,
+    const int32_t *__restrict__ gt_labels, int N, int G, int C, float img_h, float img_w,
+    float neg_thr, float pos_thr, float *__restrict__ out_reg, float *__restrict__ out_lab,
+    int32_t *__restrict__ out_idx, int8_t *__restrict__ out_state, float *__restrict__ out_iou,
+    uint32_t tiles_per_image, uint32_t d_magic)
+{
+    __shared__ float s_reg[ME_TILE * 5];
+    __shared__ uint32_t s_ls[ME_TILE];          // (label + 1) | (state + 1) << 16
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t b = blk / tiles_per_image;
+    const uint32_t n0 = (blk - b * tiles_per_image) * ME_TILE;
+    const uint32_t n = n0 + tid;
+    const bool live = n < (uint32_t)N;
+    const uint32_t tile_n = min((uint32_t)ME_TILE, (uint32_t)N - n0);
+
+    const TileMatch tm = match_tile(anchors, gt_boxes, gt_labels, b, n0, N, G, C, img_h, img_w, neg_thr, pos_thr);
+    const float4 a = tm.a;
+    const float best_iou = tm.best_iou;
+    const int best = tm.best, state = tm.state, label = tm.label;
+    const float4 *gtb = gt_boxes + (size_t)b * G;
 
     const size_t row = (size_t)b * N + n;
     if (live) {
@@ -263,6 +298,211 @@ __global__ __launch_bounds__(ME_TILE) void match_encode_kernel(
             divmod_u32(done + tid, d, d_magic, q, r);
             p[done + tid] = element(s_ls[q], r);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused matcher + loss: the consumer of the targets, metric.py:97-123
+// (ModelMetric.__call__) with focal_loss (metric.py:9-38) and tf.keras.losses.Huber, evaluated
+// straight from (match, state, offsets) -- the one-hot [B,N,C+1] tensor (90 % of the bytes of
+// match+encode) and the [B,N,5] regression tensor are never written or read back.
+//
+//   class_sum = sum over not-ignored anchors and all C classes of
+//                 -alpha_t * pow(1 - pt, gamma) * log(pt),  p = clip(pred, 1e-6, 1 - 1e-6),
+//                 pt = y ? p : 1 - p,  alpha_t = y ? alpha : 1 - alpha,  y = (class == matched label)
+//   dist_sum  = sum over foreground anchors of mean_4(huber_delta(pred_box - target_offsets))
+//   npos      = number of foreground anchors (the reference's normaliser, metric.py:108-109)
+//
+// One block = the same 256-anchor tile as match_encode_kernel; phase 3 streams the tile's
+// [tile, C] prediction rows as one flat run of 16-byte loads.  Per-block partial sums go to a
+// small buffer and are added up in double by loss_reduce_kernel in a fixed order, so the result
+// does not depend on scheduling.  Optional gradients of the UNNORMALISED sums w.r.t. the
+// predictions (d class_sum / d pred_scores, d dist_sum / d pred_boxes); the caller divides by
+// npos like the reference does (metric.py:121-123).
+// ------------------------------------------------------------------------------------------
+struct LossParams {
+    float gamma, alpha, delta;
+};
+
+__device__ __forceinline__ float focal_term(float pred, bool y, const LossParams lp, float *grad)
+{
+    const float eps = 1e-6f;
+    const float p = fminf(fmaxf(pred, eps), 1.0f - eps);                 // metric.py:22-23
+    const float alpha_t = y ? lp.alpha : 1.0f - lp.alpha;                // :25-26
+    const float pt = y ? p : 1.0f - p;                                   // :28
+    const float om = 1.0f - pt;
+    const float w = powf(om, lp.gamma);
+    const float lg = logf(pt);
+    const float loss = (-alpha_t * w) * lg;                              // :30
+    if (grad) {
+        // d/dpt [-a (1-pt)^g log pt] = a [ g (1-pt)^(g-1) log pt - (1-pt)^g / pt ];  dpt/dp = y ? 1 : -1;
+        // clip_by_value passes the gradient only inside [eps, 1-eps]
+        const float dpt = alpha_t * (lp.gamma * powf(om, lp.gamma - 1.0f) * lg - w / pt);
+        const bool inside = pred >= eps && pred <= 1.0f - eps;
+        *grad = inside ? (y ? dpt : -dpt) : 0.0f;
+    }
+    return loss;
+}
+
+template <bool GRADS>
+__global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
+    const float4 *__restrict__ anchors, const float4 *__restrict__ gt_boxes,
+    const int32_t *__restrict__ gt_labels, int N, int G, int C, float img_h, float img_w,
+    float neg_thr, float pos_thr, const float4 *__restrict__ pred_boxes, const float *__restrict__ pred_scores,
+    LossParams lp, float4 *__restrict__ grad_boxes, float *__restrict__ grad_scores,
+    float *__restrict__ partials, uint32_t tiles_per_image, uint32_t c_magic)
+{
+    __shared__ uint32_t s_ls[ME_TILE];          // (label + 1) | (state + 1) << 16
+    __shared__ float s_red[3][ME_TILE / WAVE];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t b = blk / tiles_per_image;
+    const uint32_t n0 = (blk - b * tiles_per_image) * ME_TILE;
+    const uint32_t tile_n = min((uint32_t)ME_TILE, (uint32_t)N - n0);
+
+    const TileMatch tm = match_tile(anchors, gt_boxes, gt_labels, b, n0, N, G, C, img_h, img_w, neg_thr, pos_thr);
+    s_ls[tid] = (uint32_t)(tm.label + 1) | ((uint32_t)(tm.state + 1) << 16);
+
+    // ---- box loss: Huber over the 4 offsets of every foreground anchor ------------------------
+    float dist = 0.0f, npos = 0.0f;
+    const size_t row = (size_t)b * N + n0 + tid;
+    if (tm.live) {
+        float4 gbox = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tm.state == 1) {
+            const float4 a = tm.a;
+            const float4 g = gt_boxes[(size_t)b * G + tm.best];
+            const float aw = a.z - a.x, ah = a.w - a.y;
+            const float t[4] = {(((g.x - a.x) / aw) - 0.0f) / 0.2f, (((g.y - a.y) / ah) - 0.0f) / 0.2f,
+                                (((g.z - a.z) / aw) - 0.0f) / 0.2f, (((g.w - a.w) / ah) - 0.0f) / 0.2f};   // anchors.py:286-297
+            const float4 pb = pred_boxes[row];
+            const float e[4] = {pb.x - t[0], pb.y - t[1], pb.z - t[2], pb.w - t[3]};
+            float h = 0.0f, ge[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float ae = fabsf(e[k]);
+                const bool quad = ae <= lp.delta;
+                h += quad ? 0.5f * (e[k] * e[k]) : lp.delta * ae - 0.5f * (lp.delta * lp.delta);
+                ge[k] = (quad ? e[k] : (e[k] > 0.0f ? lp.delta : -lp.delta)) * 0.25f;
+            }
+            dist = h * 0.25f;                                             // K.mean over the 4 coordinates
+            npos = 1.0f;
+            gbox = make_float4(ge[0], ge[1], ge[2], ge[3]);
+        }
+        if (GRADS && grad_boxes) grad_boxes[row] = gbox;
+    }
+    __syncthreads();
+
+    // ---- class loss: focal loss over the tile's [tile_n, C] predictions, flat 16-byte loads ----
+    float cls = 0.0f;
+    {
+        const uint32_t d = (uint32_t)C;
+        const size_t off = ((size_t)b * N + n0) * d;
+        const float *p = pred_scores + off;
+        float *gp = GRADS ? grad_scores + off : nullptr;
+        const uint32_t count = tile_n * d;
+        const uint32_t head = min(count, (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) >> 2);
+        const uint32_t nvec = (count - head) >> 2;
+        auto one = [&](uint32_t e) {
+            uint32_t q, r;
+            divmod_u32(e, d, c_magic, q, r);
+            const uint32_t ls = s_ls[q];
+            float g = 0.0f, l = 0.0f;
+            if ((ls >> 16) != 0u) l = focal_term(p[e], r + 1 == (ls & 0xffffu), lp, GRADS ? &g : nullptr);
+            cls += l;
+            if (GRADS) gp[e] = g;
+        };
+        if (tid < head) one(tid);
+        for (uint32_t v = tid; v < nvec; v += ME_TILE) {
+            const uint32_t e = head + 4 * v;
+            uint32_t q, r;
+            divmod_u32(e, d, c_magic, q, r);
+            uint32_t ls = s_ls[q];
+            const float4 pv = *reinterpret_cast<const float4 *>(p + e);
+            const float in[4] = {pv.x, pv.y, pv.z, pv.w};
+            float g[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                g[k] = 0.0f;
+                if ((ls >> 16) != 0u)                                     // state != -1 (not ignored)
+                    cls += focal_term(in[k], r + 1 == (ls & 0xffffu), lp, GRADS ? &g[k] : nullptr);
+                if (++r == d) {
+                    r = 0;
+                    ++q;
+                    ls = s_ls[min(q, (uint32_t)ME_TILE - 1)];
+                }
+            }
+            if (GRADS) *reinterpret_cast<float4 *>(gp + e) = make_float4(g[0], g[1], g[2], g[3]);
+        }
+        const uint32_t done = head + 4 * nvec;
+        if (tid < count - done) one(done + tid);
+    }
+
+    // ---- block partial sums (wave shuffle, then one thread adds the 4 wave sums in order) ------
+    float v3[3] = {cls, dist, npos};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float x = v3[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        if ((tid & 63u) == 0) s_red[k][tid >> 6] = x;
+    }
+    __syncthreads();
+    if (tid < 3) {
+        float x = 0.0f;
+        for (int w = 0; w < ME_TILE / WAVE; ++w) x += s_red[tid][w];
+        partials[(size_t)blk * 3 + tid] = x;
+    }
+}
+
+// metric.py:9-38 focal_loss on dense targets (y_true == 1 marks the positive class), summed over
+// all n elements; used for the whole-image classifier head (metric.py:132-134).  Per-block
+// partials in slot 0 of the [nblocks, 3] buffer.
+__global__ __launch_bounds__(256) void focal_dense_kernel(const float *__restrict__ y_true,
+                                                          const float *__restrict__ y_pred, size_t n, LossParams lp,
+                                                          float *__restrict__ grad, float *__restrict__ partials)
+{
+    __shared__ float s_red[4];
+    float acc = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) {
+        float g = 0.0f;
+        acc += focal_term(y_pred[i], y_true[i] == 1.0f, lp, grad ? &g : nullptr);
+        if (grad) grad[i] = g;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[(size_t)blockIdx.x * 3 + 0] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+        partials[(size_t)blockIdx.x * 3 + 1] = 0.0f;
+        partials[(size_t)blockIdx.x * 3 + 2] = 0.0f;
+    }
+}
+
+// partials [nblocks, 3] (class_sum, dist_sum, npos) -> out[0] = dist_loss, out[1] = class_loss (both
+// divided by npos when npos != 0, metric.py:121-123), out[2] = npos, out[3] = 0; sums in double,
+// fixed order.
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float *__restrict__ partials, uint32_t nblocks,
+                                                          float *__restrict__ out)
+{
+    __shared__ double s_acc[3][256];
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (uint32_t i = threadIdx.x; i < nblocks; i += 256)
+        for (int k = 0; k < 3; ++k) acc[k] += (double)partials[(size_t)i * 3 + k];
+    for (int k = 0; k < 3; ++k) s_acc[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    for (uint32_t off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off)
+            for (int k = 0; k < 3; ++k) s_acc[k][threadIdx.x] += s_acc[k][threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double cls = s_acc[0][0], dist = s_acc[1][0], npos = s_acc[2][0];
+        out[0] = (float)(npos != 0.0 ? dist / npos : dist);
+        out[1] = (float)(npos != 0.0 ? cls / npos : cls);
+        out[2] = (float)npos;
+        out[3] = 0.0f;
     }
 }
 
@@ -376,6 +616,84 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
                        neg_thr, pos_thr, out_regression, out_labels, out_match_idx, out_state, out_max_iou,
                        (uint32_t)tiles, magic);
     return launch_status("match_encode");
+}
+
+size_t odbox_match_loss_workspace(int B, int N)
+{
+    if (B < 1 || N < 1) return 0;
+    const size_t tiles = ((size_t)N + ME_TILE - 1) / ME_TILE;
+    return (tiles * (size_t)B * 3 * sizeof(float) + 255) / 256 * 256;
+}
+
+int odbox_match_loss(const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B, int N, int G,
+                     int C, float img_h, float img_w, float neg_thr, float pos_thr, const float *pred_boxes,
+                     const float *pred_scores, float gamma, float alpha, float huber_delta, float *out_loss,
+                     float *grad_boxes, float *grad_scores, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (B < 1 || N < 1 || G < 1 || C < 1 || C > ODBOX_MAX_CLASSES)
+        return fail(ODBOX_EINVAL, "odbox_match_loss: bad shape B=%d N=%d G=%d C=%d (need B,N,G>=1, 1<=C<=%d)", B, N, G, C,
+                    ODBOX_MAX_CLASSES);
+    if (!anchors || !gt_boxes || !gt_labels || !pred_boxes || !pred_scores || !out_loss)
+        return fail(ODBOX_EINVAL, "odbox_match_loss: NULL pointer");
+    if ((grad_boxes == nullptr) != (grad_scores == nullptr))
+        return fail(ODBOX_EINVAL, "odbox_match_loss: pass both gradient buffers or neither");
+    if (!aligned16(anchors) || !aligned16(gt_boxes) || !aligned16(pred_boxes) || (grad_boxes && !aligned16(grad_boxes)))
+        return fail(ODBOX_EINVAL, "odbox_match_loss: box tensors must be 16-byte aligned");
+    if (((uintptr_t)pred_scores & 3u) || (grad_scores && ((uintptr_t)pred_scores & 15u) != ((uintptr_t)grad_scores & 15u)))
+        return fail(ODBOX_EINVAL, "odbox_match_loss: grad_scores must have the 16-byte phase of pred_scores");
+    const size_t need = odbox_match_loss_workspace(B, N);
+    if (!workspace || workspace_bytes < need)
+        return fail(ODBOX_ENOSPC, "odbox_match_loss: workspace %zu bytes, need %zu", workspace_bytes, need);
+    const uint64_t tiles = ((uint64_t)N + ME_TILE - 1) / ME_TILE;
+    const uint64_t blocks = tiles * (uint64_t)B;
+    if (blocks > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_match_loss: grid too large");
+    const uint32_t d = (uint32_t)C;
+    const uint32_t magic = d == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / d);
+    const LossParams lp = {gamma, alpha, huber_delta};
+    hipStream_t st = (hipStream_t)stream;
+    if (grad_scores)
+        hipLaunchKernelGGL(match_loss_kernel<true>, dim3((uint32_t)blocks), dim3(ME_TILE), 0, st, (const float4 *)anchors,
+                           (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w, neg_thr, pos_thr,
+                           (const float4 *)pred_boxes, pred_scores, lp, (float4 *)grad_boxes, grad_scores,
+                           (float *)workspace, (uint32_t)tiles, magic);
+    else
+        hipLaunchKernelGGL(match_loss_kernel<false>, dim3((uint32_t)blocks), dim3(ME_TILE), 0, st, (const float4 *)anchors,
+                           (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w, neg_thr, pos_thr,
+                           (const float4 *)pred_boxes, pred_scores, lp, (float4 *)nullptr, (float *)nullptr,
+                           (float *)workspace, (uint32_t)tiles, magic);
+    if (int rc = launch_status("match_loss")) return rc;
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, (const float *)workspace, (uint32_t)blocks, out_loss);
+    return launch_status("loss_reduce");
+}
+
+size_t odbox_focal_loss_workspace(size_t n)
+{
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    return (blocks * 3 * sizeof(float) + 255) / 256 * 256;
+}
+
+int odbox_focal_loss(const float *y_true, const float *y_pred, size_t n, float gamma, float alpha, float *out_sum,
+                     float *grad, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!out_sum) return fail(ODBOX_EINVAL, "odbox_focal_loss: NULL out_sum");
+    if (n && (!y_true || !y_pred)) return fail(ODBOX_EINVAL, "odbox_focal_loss: NULL input");
+    const size_t need = odbox_focal_loss_workspace(n);
+    if (!workspace || workspace_bytes < need)
+        return fail(ODBOX_ENOSPC, "odbox_focal_loss: workspace %zu bytes, need %zu", workspace_bytes, need);
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    const LossParams lp = {gamma, alpha, 1.0f};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(focal_dense_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, y_true, y_pred, n, lp, grad,
+                       (float *)workspace);
+    if (int rc = launch_status("focal_dense")) return rc;
+    // reuse the 3-slot reducer: slot 0 holds the sum, npos slot is 0 so nothing is divided; the
+    // sum comes out in out[1]; out_sum must therefore have room for 4 floats
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, (const float *)workspace, (uint32_t)blocks, out_sum);
+    return launch_status("loss_reduce");
 }
 
 int odbox_bbox_overlap(const float *anchors, const float *gt_boxes, int B, int N, int G, int anchors_batched,

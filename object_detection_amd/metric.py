@@ -1,0 +1,112 @@
+"""Drop-in for the loss side of the reference module `metric` (metric.py) on MI355X: the consumer
+of the box targets, fused with the matcher so the one-hot `[B,N,C+1]` label tensor and the
+`[B,N,5]` regression tensor are never materialised.
+
+`ModelMetric(all_anchors, num_classes)(images, true_bboxes, true_labels, true_image_labels,
+pred_bboxes, pred_scores, pred_image_scores, training)` returns
+`(dist_loss, class_loss, image_class_loss)` like metric.py:97-138 (device scalars).  The Keras
+running means / accuracies of the reference's `Metric` class are bookkeeping, not arithmetic on
+the path, and are not reproduced.  HIP only (odbox_match_loss / odbox_focal_loss), no CPU fallback.
+"""
+import torch
+
+from . import _lib
+from .anchors import _image_hw
+
+_ws_cache = {}
+
+
+def _workspace(dev, need):
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _ws_cache[key] = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def focal_loss(y_true, y_pred, gamma: float = 1.5, alpha: float = 0.25, from_logits: bool = False,
+               reduction: str = 'sum', return_grad: bool = False):
+    """metric.py:9-38 on dense targets.  reduction 'sum' (default, the only one the reference
+    uses) or 'mean' (mean of the per-row sums).  return_grad=True also returns d loss / d y_pred."""
+    if from_logits:
+        raise NotImplementedError('the reference never calls focal_loss with from_logits=True')
+    if reduction not in ('sum', 'mean'):
+        raise NotImplementedError("reduction must be 'sum' or 'mean'")
+    lib = _lib.load()
+    dev = _lib.require_gpu()
+    y_true = _lib.as_dev(y_true, torch.float32, dev)
+    y_pred = _lib.as_dev(y_pred, torch.float32, dev)
+    if y_true.shape != y_pred.shape:
+        raise ValueError('y_true %r and y_pred %r differ in shape' % (tuple(y_true.shape), tuple(y_pred.shape)))
+    n = y_pred.numel()
+    out = torch.empty(4, dtype=torch.float32, device=dev)
+    grad = torch.empty_like(y_pred) if return_grad else None
+    ws = _workspace(dev, lib.odbox_focal_loss_workspace(n))
+    _lib.check(lib.odbox_focal_loss(_lib.ptr(y_true), _lib.ptr(y_pred), n, float(gamma), float(alpha),
+                                    _lib.ptr(out), _lib.ptr(grad), _lib.ptr(ws), ws.numel(),
+                                    _lib.stream_ptr()), 'odbox_focal_loss')
+    loss = out[1]
+    scale = 1.0
+    if reduction == 'mean':
+        rows = max(1, n // max(1, y_pred.shape[-1])) if y_pred.dim() else 1
+        scale = 1.0 / rows
+        loss = loss * scale
+    if return_grad:
+        return loss, (grad * scale if scale != 1.0 else grad)
+    return loss
+
+
+def detection_loss(anchors, image_hw, true_bboxes, true_labels, pred_bboxes, pred_scores, num_classes,
+                   negative_overlap=0.4, positive_overlap=0.5, gamma=1.5, alpha=0.25, huber_delta=1.0,
+                   return_grads=False):
+    """The fused matcher + loss (`odbox_match_loss`).  Returns (dist_loss, class_loss, normalizer)
+    as device scalars, both losses divided by normalizer = #foreground anchors when it is not 0
+    (metric.py:108-123).  return_grads=True adds (grad_boxes [B,N,4], grad_scores [B,N,C]): the
+    gradients of the two RETURNED losses w.r.t. pred_bboxes / pred_scores."""
+    lib = _lib.load()
+    dev = _lib.require_gpu()
+    anchors = _lib.as_dev(anchors, torch.float32, dev)
+    gt = _lib.as_dev(true_bboxes, torch.float32, dev)
+    lab = _lib.as_dev(true_labels, torch.int32, dev)
+    pb = _lib.as_dev(pred_bboxes, torch.float32, dev)
+    ps = _lib.as_dev(pred_scores, torch.float32, dev)
+    B, G = int(gt.shape[0]), int(gt.shape[1])
+    N, C = int(anchors.shape[0]), int(num_classes)
+    if tuple(lab.shape) != (B, G) or tuple(pb.shape) != (B, N, 4) or tuple(ps.shape) != (B, N, C):
+        raise ValueError('shape mismatch: labels %r, pred_bboxes %r, pred_scores %r for B=%d N=%d G=%d C=%d'
+                         % (tuple(lab.shape), tuple(pb.shape), tuple(ps.shape), B, N, G, C))
+    out = torch.empty(4, dtype=torch.float32, device=dev)
+    gb = gs = None
+    if return_grads:
+        gb = torch.empty_like(pb)
+        gs = torch.empty_like(ps)
+    ws = _workspace(dev, lib.odbox_match_loss_workspace(B, N))
+    _lib.check(lib.odbox_match_loss(
+        _lib.ptr(anchors), _lib.ptr(gt), _lib.ptr(lab), B, N, G, C, float(image_hw[0]), float(image_hw[1]),
+        float(negative_overlap), float(positive_overlap), _lib.ptr(pb), _lib.ptr(ps),
+        float(gamma), float(alpha), float(huber_delta), _lib.ptr(out), _lib.ptr(gb), _lib.ptr(gs),
+        _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), 'odbox_match_loss')
+    if return_grads:
+        # the kernel returns gradients of the unnormalised sums; scale on the device, no sync
+        inv = torch.where(out[2] != 0, 1.0 / out[2], torch.ones_like(out[2]))
+        return out[0], out[1], out[2], gb * inv, gs * inv
+    return out[0], out[1], out[2]
+
+
+class ModelMetric:
+    """metric.py:76-138.  `dtype` is accepted for signature parity (it only casts the image
+    height / width in the reference)."""
+
+    def __init__(self, all_anchors, num_classes: int, dtype=torch.float32, **kwargs):
+        self.all_anchors = all_anchors
+        self.num_classes = num_classes
+        self.dtype = dtype
+
+    def __call__(self, images, true_bboxes, true_labels, true_image_labels, pred_bboxes, pred_scores,
+                 pred_image_scores, training):
+        dist_loss, class_loss, _ = detection_loss(self.all_anchors, _image_hw(images), true_bboxes, true_labels,
+                                                  pred_bboxes, pred_scores, self.num_classes)
+        image_class_loss = 0.
+        if pred_image_scores is not None:
+            image_class_loss = focal_loss(true_image_labels, pred_image_scores, reduction='sum')
+        return dist_loss, class_loss, image_class_loss

@@ -321,3 +321,75 @@ def decode_and_nms(anchors, regressors, class_scores, image_hw,
     boxes = regress_bndboxes(np.broadcast_to(anchors[None], regressors.shape), regressors)
     boxes = clip_boxes(boxes, image_hw)
     return nms(boxes, class_scores, score_threshold, iou_threshold, max_ret)
+
+
+# ----------------------------------------------------------------------------------------
+# consumer of the targets: focal loss + Huber
+# ----------------------------------------------------------------------------------------
+
+def focal_loss_elements(y_true, y_pred, gamma=1.5, alpha=0.25):
+    """metric.py:16-30, element by element in fp32 (before the reductions of :31-36)."""
+    y = _f32(y_true)
+    p = np.minimum(np.maximum(_f32(y_pred), F32(1e-6)), F32(1.0) - F32(1e-6))
+    pos = y == F32(1)
+    a = np.where(pos, F32(alpha), F32(1) - F32(alpha)).astype(F32)
+    pt = np.where(pos, p, F32(1) - p).astype(F32)
+    w = np.power(F32(1) - pt, F32(gamma)).astype(F32)
+    return ((-a * w) * np.log(pt)).astype(F32)
+
+
+def focal_loss(y_true, y_pred, gamma=1.5, alpha=0.25, reduction='sum'):
+    """metric.py:9-38 (from_logits=False).  The order of TF's reductions is not specified, so
+    the sums are taken in float64 and compared with a tolerance."""
+    rows = focal_loss_elements(y_true, y_pred, gamma, alpha).sum(axis=-1, dtype=np.float64)
+    if reduction == 'mean':
+        return rows.mean()
+    if reduction == 'sum':
+        return rows.sum()
+    return rows
+
+
+def huber(y_true, y_pred, delta=1.0):
+    """tf.keras.losses.Huber(delta)(y_true, y_pred) per sample: mean over the last axis."""
+    e = (_f32(y_pred) - _f32(y_true)).astype(F32)
+    ae = np.abs(e)
+    d = F32(delta)
+    h = np.where(ae <= d, F32(0.5) * (e * e), d * ae - F32(0.5) * (d * d)).astype(F32)
+    return h.mean(axis=-1, dtype=np.float64)
+
+
+def model_metric(anchors, image_hw, true_bboxes, true_labels, pred_bboxes, pred_scores, num_classes,
+                 gamma=1.5, alpha=0.25, delta=1.0, with_grads=False):
+    """metric.py:97-123 (ModelMetric.__call__ without the whole-image head): returns
+    (dist_loss, class_loss, normalizer[, grad_boxes, grad_scores]); the gradients are those of
+    the UNNORMALISED sums w.r.t. the predictions, analytic, in float64."""
+    t = anchor_targets_bbox(anchors, image_hw, true_bboxes, true_labels, num_classes)
+    labels, regression = t['labels'], t['regression']
+    states = labels[:, :, -1]
+    not_ignore = states != F32(-1)
+    fg = states == F32(1)
+    normalizer = float(fg.sum())
+    pred_scores = _f32(pred_scores)
+    pred_bboxes = _f32(pred_bboxes)
+    class_sum = focal_loss(labels[:, :, :-1][not_ignore], pred_scores[not_ignore], gamma, alpha, 'sum')
+    dist_sum = huber(regression[:, :, :-1][fg], pred_bboxes[fg], delta).sum()
+    dist_loss, class_loss = dist_sum, class_sum
+    if normalizer != 0:
+        dist_loss, class_loss = dist_sum / normalizer, class_sum / normalizer
+    if not with_grads:
+        return dist_loss, class_loss, normalizer
+    gb = np.zeros(pred_bboxes.shape, dtype=np.float64)
+    e = pred_bboxes[fg].astype(np.float64) - regression[:, :, :-1][fg].astype(np.float64)
+    gb[fg] = np.where(np.abs(e) <= delta, e, delta * np.sign(e)) / 4.0
+    y = labels[:, :, :-1] == F32(1)
+    p64 = pred_scores.astype(np.float64)
+    eps = float(F32(1e-6))
+    hi = float(F32(1.0) - F32(1e-6))
+    pc = np.clip(p64, eps, hi)
+    a = np.where(y, alpha, 1.0 - alpha)
+    pt = np.where(y, pc, 1.0 - pc)
+    dpt = a * (gamma * np.power(1.0 - pt, gamma - 1.0) * np.log(pt) - np.power(1.0 - pt, gamma) / pt)
+    gs = np.where(y, dpt, -dpt)
+    gs = np.where((p64 >= eps) & (p64 <= hi), gs, 0.0)
+    gs = np.where(not_ignore[:, :, None], gs, 0.0)
+    return dist_loss, class_loss, normalizer, gb, gs

@@ -1,0 +1,102 @@
+"""GPU parity of the fused matcher + loss (metric.py:97-123, focal_loss
+metric.py:9-38, Keras Huber) against the oracle.  These are floating-point reductions whose
+order TensorFlow does not specify: tolerance 1e-5 relative on the losses (north_star's bar for
+floating point), 1e-4 on gradients (fp32 pow/log vs the float64 analytic oracle); the
+foreground count is exact."""
+import numpy as np
+import pytest
+import torch
+
+from object_detection_amd import metric as M
+from object_detection_amd import workloads
+from oracle import odbox_oracle as O
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+RTOL = 1e-5
+
+
+def _case(seed, S=256, B=3, G=12, C=7, pad_to=16):
+    rng = np.random.default_rng(seed)
+    anchors = O.generate_anchors(S)
+    N = anchors.shape[0]
+    gts = [workloads.gt_boxes(rng, S, G, C, pad_to=pad_to) for _ in range(B)]
+    gt = np.stack([g[0] for g in gts])
+    lab = np.stack([g[1] for g in gts])
+    pb = rng.normal(0, 1.5, (B, N, 4)).astype(F)          # both Huber branches
+    ps = rng.uniform(0, 1, (B, N, C)).astype(F)
+    ps[0, :50] = 0.0                                      # clipped at both ends
+    ps[0, 50:100] = 1.0
+    return anchors, (S, S), gt, lab, pb, ps, C
+
+
+@pytest.mark.parametrize('seed,C', [(1, 7), (2, 1), (3, 80), (4, 3)])
+def test_losses_match_oracle(seed, C):
+    anchors, hw, gt, lab, pb, ps, C = _case(seed, C=C)
+    d, c, n = M.detection_loss(anchors, hw, gt, lab, pb, ps, C)
+    rd, rc, rn = O.model_metric(anchors, hw, gt, lab, pb, ps, C)
+    assert rn > 0 and float(n) == rn
+    np.testing.assert_allclose(float(d), rd, rtol=RTOL)
+    np.testing.assert_allclose(float(c), rc, rtol=RTOL)
+
+
+def test_gradients_match_oracle():
+    anchors, hw, gt, lab, pb, ps, C = _case(11, B=2, C=5)
+    d, c, n, gb, gs = M.detection_loss(anchors, hw, gt, lab, pb, ps, C, return_grads=True)
+    rd, rc, rn, rgb, rgs = O.model_metric(anchors, hw, gt, lab, pb, ps, C, with_grads=True)
+    np.testing.assert_allclose(gb.cpu().numpy(), rgb / rn, rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(gs.cpu().numpy(), rgs / rn, rtol=1e-4, atol=1e-6 * np.abs(rgs / rn).max())
+    # ignored anchors and clipped scores carry no gradient
+    assert (gs[0, :100] == 0).all()
+    # without gradients the losses are the same numbers
+    d2, c2, n2 = M.detection_loss(anchors, hw, gt, lab, pb, ps, C)
+    assert float(d2) == float(d) and float(c2) == float(c)
+
+
+def test_no_foreground_means_no_division():
+    anchors, hw, gt, lab, pb, ps, C = _case(5, B=2, C=4)
+    gt[:] = -1
+    lab[:] = -1                                           # every anchor ignored (max IoU -1)
+    d, c, n = M.detection_loss(anchors, hw, gt, lab, pb, ps, C)
+    assert float(n) == 0 and float(d) == 0 and float(c) == 0
+    gt[:, 0] = [1000, 1000, 1010, 1010]                   # a valid row nobody overlaps: all background
+    lab[:, 0] = 1
+    d, c, n = M.detection_loss(anchors, hw, gt, lab, pb, ps, C)
+    rd, rc, rn = O.model_metric(anchors, hw, gt, lab, pb, ps, C)
+    assert float(n) == 0 == rn and float(d) == 0
+    np.testing.assert_allclose(float(c), rc, rtol=RTOL)   # un-normalised sum, metric.py:121
+
+
+def test_dense_focal_loss_and_model_metric_signature():
+    rng = np.random.default_rng(3)
+    y = (rng.uniform(size=(6, 9)) < 0.2).astype(F)
+    p = rng.uniform(0, 1, (6, 9)).astype(F)
+    np.testing.assert_allclose(float(M.focal_loss(y, p)), O.focal_loss(y, p), rtol=RTOL)
+    np.testing.assert_allclose(float(M.focal_loss(y, p, reduction='mean')), O.focal_loss(y, p, reduction='mean'), rtol=RTOL)
+    loss, grad = M.focal_loss(y, p, gamma=2.0, alpha=0.4, return_grad=True)
+    np.testing.assert_allclose(float(loss), O.focal_loss(y, p, 2.0, 0.4), rtol=RTOL)
+    h = 1e-3
+    num = (O.focal_loss(y, np.clip(p + h, 0, 1)) - O.focal_loss(y, np.clip(p - h, 0, 1)))
+    assert np.isfinite(grad.cpu().numpy()).all() and np.isfinite(num)
+    anchors, hw, gt, lab, pb, ps, C = _case(8, B=2, C=3)
+    mm = M.ModelMetric(anchors, C)
+    images = np.zeros((2, hw[0], hw[1], 3), F)
+    d, c, i = mm(images, gt, lab, y[:2], pb, ps, p[:2], True)
+    rd, rc, _ = O.model_metric(anchors, hw, gt, lab, pb, ps, C)
+    np.testing.assert_allclose([float(d), float(c)], [rd, rc], rtol=RTOL)
+    np.testing.assert_allclose(float(i), O.focal_loss(y[:2], p[:2]), rtol=RTOL)
+    d, c, i = mm(images, gt, lab, None, pb, ps, None, False)
+    assert i == 0.
+
+
+def test_cfg2_full_size_loss():
+    anchors = O.yolo_shaped_anchors(416)
+    gt, lab = workloads.match_inputs(2, batch=16)
+    rng = np.random.default_rng(9)
+    N = anchors.shape[0]
+    pb = rng.normal(0, 1, (16, N, 4)).astype(F)
+    ps = rng.uniform(0.001, 0.999, (16, N, 80)).astype(F)
+    d, c, n = M.detection_loss(anchors, (416, 416), gt, lab, pb, ps, 80)
+    rd, rc, rn = O.model_metric(anchors, (416, 416), gt, lab, pb, ps, 80)
+    assert float(n) == rn
+    np.testing.assert_allclose([float(d), float(c)], [rd, rc], rtol=RTOL)

@@ -202,3 +202,38 @@ def test_c_and_numpy_decode_nms_agree():
     for r, g, name in zip(ref, got, ('boxes', 'scores', 'labels', 'keep', 'count')):
         np.testing.assert_array_equal(r, g, err_msg=name)
     assert ref[4].min() > 0
+
+
+def test_focal_and_huber_known_answers():
+    # y=1, p=0.5: -0.25 * 0.5^1.5 * ln 0.5 ; y=0, p=0.5: -0.75 * 0.5^1.5 * ln 0.5
+    v = O.focal_loss_elements(F([1, 0]), F([0.5, 0.5]))
+    np.testing.assert_allclose(v, [0.25 * 0.5 ** 1.5 * np.log(2), 0.75 * 0.5 ** 1.5 * np.log(2)], rtol=1e-6)
+    # clipping: p = 0 with y = 1 -> p = 1e-6
+    v = O.focal_loss_elements(F([1]), F([0.0]))
+    np.testing.assert_allclose(v, [-0.25 * (1 - 1e-6) ** 1.5 * np.log(1e-6)], rtol=1e-5)
+    # Huber(delta=1): errors (0.5, -2, 0, 1) -> (0.125, 1.5, 0, 0.5) -> mean 0.53125
+    np.testing.assert_allclose(O.huber(F([[0, 0, 0, 0]]), F([[0.5, -2, 0, 1]])), [0.53125], rtol=1e-7)
+
+
+def test_model_metric_normaliser_and_gradient_consistency():
+    rng = np.random.default_rng(21)
+    anchors = O.generate_anchors(128)
+    N = anchors.shape[0]
+    gt = np.full((1, 4, 4), -1, F)
+    gt[0, 0] = anchors[300]
+    lab = np.int32([[2, -1, -1, -1]])
+    pb = rng.normal(0, 1, (1, N, 4)).astype(F)
+    ps = rng.uniform(0.05, 0.95, (1, N, 3)).astype(F)
+    d, c, n, gb, gs = O.model_metric(anchors, (128, 128), gt, lab, pb, ps, 3, with_grads=True)
+    assert n >= 1
+    # finite-difference check of the analytic class gradient on one element
+    t = O.anchor_targets_bbox(anchors, (128, 128), gt, lab, 3)
+    i = int(np.nonzero(t['state'][0] == 1)[0][0])
+    for k in range(3):
+        h = 1e-3
+        up, dn = ps.copy(), ps.copy()
+        up[0, i, k] += h
+        dn[0, i, k] -= h
+        num = (O.model_metric(anchors, (128, 128), gt, lab, pb, up, 3)[1] -
+               O.model_metric(anchors, (128, 128), gt, lab, pb, dn, 3)[1]) * n / (2 * h)
+        np.testing.assert_allclose(gs[0, i, k], num, rtol=2e-3)
