@@ -81,6 +81,30 @@ def main():
             row['Tops'] = ops / t / 1e12
             row['frac_valu_nonpacked'] = ops / t / VALU_OPS
         rows.append(row)
+    # fused matcher + loss on the cfg-2 batch (forward, and forward + gradients)
+    if 2 in args.cfg:
+        c = workloads.CONFIGS[2]
+        anchors = grid(2)
+        N, B, C = anchors.shape[0], 64, c['C']
+        gt, lab = workloads.match_inputs(2, batch=B)
+        gt, lab = torch.as_tensor(gt).to(dev), torch.as_tensor(lab).to(dev)
+        G = gt.shape[1]
+        pb = torch.randn((B, N, 4), device=dev)
+        ps = torch.rand((B, N, C), device=dev)
+        out = torch.empty(4, device=dev)
+        gb, gs = torch.empty_like(pb), torch.empty_like(ps)
+        ws = torch.empty(lib.odbox_match_loss_workspace(B, N), dtype=torch.uint8, device=dev)
+        for name, g1, g2 in (('2_loss_fwd', None, None), ('2_loss_fwd_bwd', gb, gs)):
+            def step():
+                rc = lib.odbox_match_loss(anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C, float(c['S']),
+                                          float(c['S']), 0.4, 0.5, pb.data_ptr(), ps.data_ptr(), 1.5, 0.25, 1.0,
+                                          out.data_ptr(), None if g1 is None else g1.data_ptr(),
+                                          None if g2 is None else g2.data_ptr(), ws.data_ptr(), ws.numel(), st)
+                assert rc == 0
+            t = event_time(step, args.iters)
+            byts = B * (N * (32 + 4 * C) + 20 * G) * (1 if g1 is None else 2)
+            rows.append(dict(cfg=name, B=B, N=N, G=G, C=C, us=t * 1e6, img_s=B / t, GBs=byts / t / 1e9,
+                             frac_hbm=byts / t / 1e9 / HBM))
     for r in rows:
         print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}))
 
