@@ -9,6 +9,7 @@
 //
 // Reference citations are file:line under the reference tree (bioothod/object_detection).
 #include "odbox_common.h"
+#include <type_traits>
 
 namespace odbox {
 
@@ -320,44 +321,76 @@ __global__ __launch_bounds__(ME_TILE) void match_encode_kernel(
 // predictions (d class_sum / d pred_scores, d dist_sum / d pred_boxes); the caller divides by
 // npos like the reference does (metric.py:121-123).
 // ------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+
 struct LossParams {
     float gamma, alpha, delta;
 };
 
-// One focal-loss element.  This is floating-point work compared with a tolerance (1e-5 relative on
-// the sums), so the transcendental parts use the hardware rate instructions: log through
-// v_log_f32, pow(x, gamma) as x * sqrt(x) for the reference's gamma = 1.5 (v_sqrt_f32) and through
-// exp2(gamma * log2 x) otherwise -- about 10 instructions per element instead of ~60 for the
-// correctly rounded powf / logf, which made the kernel VALU-bound (291 us vs 45 us for the
-// cfg-2 batch).
-__device__ __forceinline__ float fast_pow(float x, float g, bool g_is_1p5)
+// One focal-loss element, branch-free.  This is floating-point work compared with a tolerance
+// (1e-5 relative on the sums), so the transcendental parts use the hardware rate instructions:
+// log2 through v_log_f32 (pt >= 1e-6, never denormal), pow(x, gamma) as x * sqrt(x) for the
+// reference's gamma = 1.5 (v_sqrt_f32) and exp2(gamma * log2 x) otherwise -- about 12 instructions
+// per element instead of ~60 for the correctly rounded powf / logf, which made the kernel
+// VALU-bound (291 us vs 45 us of HBM time for the cfg-2 batch).
+template <bool G15, bool GRAD>
+__device__ __forceinline__ float focal_term(float pred, bool y, const LossParams lp, float &grad)
 {
-    return g_is_1p5 ? x * __builtin_amdgcn_sqrtf(x) : __powf(x, g);
-}
-
-__device__ __forceinline__ float focal_term(float pred, bool y, const LossParams lp, float *grad)
-{
-    const float eps = 1e-6f;
-    const bool g15 = lp.gamma == 1.5f;                                   // wave-uniform
+    const float eps = 1e-6f, ln2 = 0.69314718f;
     const float p = fminf(fmaxf(pred, eps), 1.0f - eps);                 // metric.py:22-23
-    const float alpha_t = y ? lp.alpha : 1.0f - lp.alpha;                // :25-26
-    const float pt = y ? p : 1.0f - p;                                   // :28
+    const float q = 1.0f - p;
+    const float pt = y ? p : q;                                          // :28
     const float om = 1.0f - pt;
-    const float w = fast_pow(om, lp.gamma, g15);
-    const float lg = __logf(pt);
-    const float loss = (-alpha_t * w) * lg;                              // :30
-    if (grad) {
+    const float alpha_t = y ? lp.alpha : 1.0f - lp.alpha;                // :25-26
+    const float l2 = __builtin_amdgcn_logf(pt);                          // log2(pt)
+    float w, lom = 0.0f;
+    if (G15) {
+        w = om * __builtin_amdgcn_sqrtf(om);
+    } else {
+        lom = __builtin_amdgcn_logf(om);
+        w = __builtin_amdgcn_exp2f(lp.gamma * lom);
+    }
+    const float lg = ln2 * l2;
+    if (GRAD) {
         // d/dpt [-a (1-pt)^g log pt] = a [ g (1-pt)^(g-1) log pt - (1-pt)^g / pt ];  dpt/dp = y ? 1 : -1;
         // clip_by_value passes the gradient only inside [eps, 1-eps]
-        const float wm1 = g15 ? __builtin_amdgcn_sqrtf(om) : __powf(om, lp.gamma - 1.0f);
-        const float dpt = alpha_t * (lp.gamma * wm1 * lg - __fdividef(w, pt));
+        const float wm1 = G15 ? __builtin_amdgcn_sqrtf(om) : __builtin_amdgcn_exp2f((lp.gamma - 1.0f) * lom);
+        const float dpt = alpha_t * (lp.gamma * wm1 * lg - w * __builtin_amdgcn_rcpf(pt));
         const bool inside = pred >= eps && pred <= 1.0f - eps;
-        *grad = inside ? (y ? dpt : -dpt) : 0.0f;
+        grad = inside ? (y ? dpt : -dpt) : 0.0f;
     }
-    return loss;
+    return (-alpha_t * w) * lg;                                          // :30
 }
 
-template <bool GRADS>
+// The same element for y = 0 (pt = 1 - p), which is all but one element per foreground anchor: no
+// label logic at all in the streaming loop; the matched class of a foreground anchor is corrected
+// afterwards by that anchor's thread (match_loss_kernel).  cneg = -(1 - alpha) * ln2.
+template <bool G15, bool GRAD>
+__device__ __forceinline__ float focal_neg(float pred, const LossParams lp, float cneg, float &grad)
+{
+    const float eps = 1e-6f, ln2 = 0.69314718f;
+    const float p = __builtin_amdgcn_fmed3f(pred, eps, 1.0f - eps);
+    const float pt = 1.0f - p;
+    const float om = 1.0f - pt;
+    const float l2 = __builtin_amdgcn_logf(pt);
+    float w, wm1, lom = 0.0f;
+    if (G15) {
+        wm1 = __builtin_amdgcn_sqrtf(om);
+        w = om * wm1;
+    } else {
+        lom = __builtin_amdgcn_logf(om);
+        w = __builtin_amdgcn_exp2f(lp.gamma * lom);
+        wm1 = GRAD ? __builtin_amdgcn_exp2f((lp.gamma - 1.0f) * lom) : 0.0f;
+    }
+    if (GRAD) {
+        // dL/dp = -dL/dpt = (1 - alpha) [ w / pt - gamma wm1 log pt ], zero where the clip is active
+        const float gneg = (1.0f - lp.alpha) * (w * __builtin_amdgcn_rcpf(pt) - (lp.gamma * ln2) * wm1 * l2);
+        grad = p == pred ? gneg : 0.0f;
+    }
+    return (cneg * w) * l2;
+}
+
+template <bool GRADS, bool G15, bool ALIGNED>
 __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     const float4 *__restrict__ anchors, const float4 *__restrict__ gt_boxes,
     const int32_t *__restrict__ gt_labels, int N, int G, int C, float img_h, float img_w,
@@ -365,7 +398,7 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     LossParams lp, float4 *__restrict__ grad_boxes, float *__restrict__ grad_scores,
     float *__restrict__ partials, uint32_t tiles_per_image, uint32_t c_magic)
 {
-    __shared__ uint32_t s_ls[ME_TILE];          // (label + 1) | (state + 1) << 16
+    __shared__ float s_live[ME_TILE];           // 1.0 = anchor counts (state != -1), 0.0 = ignored
     __shared__ float s_red[3][ME_TILE / WAVE];
 
     const uint32_t tid = threadIdx.x;
@@ -374,8 +407,27 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     const uint32_t n0 = (blk - b * tiles_per_image) * ME_TILE;
     const uint32_t tile_n = min((uint32_t)ME_TILE, (uint32_t)N - n0);
 
+    // The tile's [tile_n, C] predictions are one contiguous run: 16-byte loads over the flat element
+    // range (scalar head / tail for the 4-byte-aligned ends; ALIGNED = C % 4 == 0 and a 16-byte
+    // aligned tensor: no head, and a vector never straddles two anchors).  The first load is issued
+    // before the match so its latency hides behind the GT loop.
+    const uint32_t d = (uint32_t)C;
+    const size_t soff = ((size_t)b * N + n0) * d;
+    const float *p = pred_scores + soff;
+    const uint32_t count = tile_n * d;
+    const uint32_t head = ALIGNED ? 0u : min(count, (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) >> 2);
+    const uint32_t nvec = (count - head) >> 2;
+    const v4f *pv4 = reinterpret_cast<const v4f *>(p + head);
+    v4f cur = {0.5f, 0.5f, 0.5f, 0.5f};
+    if (d >= 4 && nvec) cur = pv4[min(tid, nvec - 1)];
+
     const TileMatch tm = match_tile(anchors, gt_boxes, gt_labels, b, n0, N, G, C, img_h, img_w, neg_thr, pos_thr);
-    s_ls[tid] = (uint32_t)(tm.label + 1) | ((uint32_t)(tm.state + 1) << 16);
+    s_live[tid] = tm.live && tm.state != -1 ? 1.0f : 0.0f;
+
+    // the one y = 1 element of a foreground anchor: fetch it now, correct the sum after the stream
+    const bool has_pos = tm.live && tm.state == 1 && tm.label >= 0;
+    const uint32_t pos_e = tid * d + (uint32_t)max(tm.label, 0);
+    const float pos_x = has_pos ? p[pos_e] : 0.5f;
 
     // ---- box loss: Huber over the 4 offsets of every foreground anchor ------------------------
     float dist = 0.0f, npos = 0.0f;
@@ -406,49 +458,70 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     }
     __syncthreads();
 
-    // ---- class loss: focal loss over the tile's [tile_n, C] predictions, flat 16-byte loads ----
+    // ---- class loss: every element as y = 0, masked by its anchor's live flag ------------------
+    const float cneg = -(1.0f - lp.alpha) * 0.69314718f;
     float cls = 0.0f;
+    float *gp = GRADS ? grad_scores + soff : nullptr;
     {
-        const uint32_t d = (uint32_t)C;
-        const size_t off = ((size_t)b * N + n0) * d;
-        const float *p = pred_scores + off;
-        float *gp = GRADS ? grad_scores + off : nullptr;
-        const uint32_t count = tile_n * d;
-        const uint32_t head = min(count, (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) >> 2);
-        const uint32_t nvec = (count - head) >> 2;
         auto one = [&](uint32_t e) {
             uint32_t q, r;
             divmod_u32(e, d, c_magic, q, r);
-            const uint32_t ls = s_ls[q];
-            float g = 0.0f, l = 0.0f;
-            if ((ls >> 16) != 0u) l = focal_term(p[e], r + 1 == (ls & 0xffffu), lp, GRADS ? &g : nullptr);
-            cls += l;
-            if (GRADS) gp[e] = g;
+            const float m = s_live[q];
+            float g = 0.0f;
+            cls += m * focal_neg<G15, GRADS>(p[e], lp, cneg, g);
+            if (GRADS) gp[e] = m * g;
         };
         if (tid < head) one(tid);
-        for (uint32_t v = tid; v < nvec; v += ME_TILE) {
-            const uint32_t e = head + 4 * v;
-            uint32_t q, r;
-            divmod_u32(e, d, c_magic, q, r);
-            uint32_t ls = s_ls[q];
-            const float4 pv = *reinterpret_cast<const float4 *>(p + e);
-            const float in[4] = {pv.x, pv.y, pv.z, pv.w};
-            float g[4];
+        if (d >= 4) {
+            for (uint32_t v = tid; v < nvec; v += ME_TILE) {
+                const v4f nxt = pv4[min(v + ME_TILE, nvec - 1)];   // prefetch, clamped => unconditional
+                const uint32_t e = head + 4 * v;
+                uint32_t q, r;
+                divmod_u32(e, d, c_magic, q, r);
+                const float m0 = s_live[q];
+                const float in[4] = {cur.x, cur.y, cur.z, cur.w};
+                float g[4] = {0.f, 0.f, 0.f, 0.f}, l[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                g[k] = 0.0f;
-                if ((ls >> 16) != 0u)                                     // state != -1 (not ignored)
-                    cls += focal_term(in[k], r + 1 == (ls & 0xffffu), lp, GRADS ? &g[k] : nullptr);
-                if (++r == d) {
-                    r = 0;
-                    ++q;
-                    ls = s_ls[min(q, (uint32_t)ME_TILE - 1)];
+                for (uint32_t k = 0; k < 4; ++k) l[k] = focal_neg<G15, GRADS>(in[k], lp, cneg, g[k]);
+                if (ALIGNED) {
+                    cls += m0 * ((l[0] + l[1]) + (l[2] + l[3]));
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) g[k] *= m0;
+                } else {
+                    // a 16-byte vector spans at most two anchors: q (elements k < left) and q + 1
+                    const float m1 = s_live[min(q + 1, (uint32_t)ME_TILE - 1)];
+                    const uint32_t left = d - r;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        const float m = k < left ? m0 : m1;
+                        cls += m * l[k];
+                        g[k] *= m;
+                    }
                 }
+                if (GRADS) {
+                    // streamed once, never re-read here: keep it out of the caches (77 vs 97 us per launch)
+                    const v4f gv = {g[0], g[1], g[2], g[3]};
+                    __builtin_nontemporal_store(gv, reinterpret_cast<v4f *>(gp + e));
+                }
+                cur = nxt;
             }
-            if (GRADS) *reinterpret_cast<float4 *>(gp + e) = make_float4(g[0], g[1], g[2], g[3]);
+        } else {
+            for (uint32_t e = head + tid; e < head + 4 * nvec; e += ME_TILE) one(e);
         }
         const uint32_t done = head + 4 * nvec;
         if (tid < count - done) one(done + tid);
+    }
+
+    // ---- the matched class of every foreground anchor: replace its y = 0 term by the y = 1 term ---
+    {
+        float g0 = 0.0f, g1 = 0.0f;
+        const float lneg = focal_neg<G15, GRADS>(pos_x, lp, cneg, g0);
+        const float lpos = focal_term<G15, GRADS>(pos_x, true, lp, g1);
+        if (has_pos) cls += lpos - lneg;
+        if (GRADS) {
+            __syncthreads();                     // the streaming stores of this tile are done
+            if (has_pos) gp[pos_e] = g1;
+        }
     }
 
     // ---- block partial sums (wave shuffle, then one thread adds the 4 wave sums in order) ------
@@ -471,6 +544,7 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
 // metric.py:9-38 focal_loss on dense targets (y_true == 1 marks the positive class), summed over
 // all n elements; used for the whole-image classifier head (metric.py:132-134).  Per-block
 // partials in slot 0 of the [nblocks, 3] buffer.
+template <bool G15>
 __global__ __launch_bounds__(256) void focal_dense_kernel(const float *__restrict__ y_true,
                                                           const float *__restrict__ y_pred, size_t n, LossParams lp,
                                                           float *__restrict__ grad, float *__restrict__ partials)
@@ -479,7 +553,7 @@ __global__ __launch_bounds__(256) void focal_dense_kernel(const float *__restric
     float acc = 0.0f;
     for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) {
         float g = 0.0f;
-        acc += focal_term(y_pred[i], y_true[i] == 1.0f, lp, grad ? &g : nullptr);
+        acc += focal_term<G15, true>(y_pred[i], y_true[i] == 1.0f, lp, g);
         if (grad) grad[i] = g;
     }
 #pragma unroll
@@ -496,22 +570,42 @@ __global__ __launch_bounds__(256) void focal_dense_kernel(const float *__restric
 // partials [nblocks, 3] (class_sum, dist_sum, npos) -> out[0] = dist_loss, out[1] = class_loss (both
 // divided by npos when npos != 0, metric.py:121-123), out[2] = npos, out[3] = 0; sums in double,
 // fixed order.
-__global__ __launch_bounds__(256) void loss_reduce_kernel(const float *__restrict__ partials, uint32_t nblocks,
-                                                          float *__restrict__ out)
+constexpr int RED_THREADS = 1024;
+__global__ __launch_bounds__(RED_THREADS) void loss_reduce_kernel(const float *__restrict__ partials, uint32_t nblocks,
+                                                                  float *__restrict__ out)
 {
-    __shared__ double s_acc[3][256];
+    // One block; a single-block kernel is pure latency, so every thread issues its loads back to
+    // back (4 rows per trip) before the first add.  Thread t owns rows t, t + 1024, ...: the
+    // summation tree is fixed by (nblocks), not by scheduling.
+    __shared__ double s_acc[3][RED_THREADS / WAVE];
     double acc[3] = {0.0, 0.0, 0.0};
-    for (uint32_t i = threadIdx.x; i < nblocks; i += 256)
-        for (int k = 0; k < 3; ++k) acc[k] += (double)partials[(size_t)i * 3 + k];
-    for (int k = 0; k < 3; ++k) s_acc[k][threadIdx.x] = acc[k];
-    __syncthreads();
-    for (uint32_t off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off)
-            for (int k = 0; k < 3; ++k) s_acc[k][threadIdx.x] += s_acc[k][threadIdx.x + off];
-        __syncthreads();
+    for (uint32_t i0 = threadIdx.x; i0 < nblocks; i0 += 4 * RED_THREADS) {
+        float v[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * RED_THREADS;
+            const bool ok = i < nblocks;
+            const size_t at = (size_t)(ok ? i : i0) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[u][k] = ok ? partials[at + k] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc[k] += (double)v[u][k];
     }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off);
+        if ((threadIdx.x & 63u) == 0) s_acc[k][threadIdx.x >> 6] = acc[k];
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const double cls = s_acc[0][0], dist = s_acc[1][0], npos = s_acc[2][0];
+        double t[3] = {0.0, 0.0, 0.0};
+        for (int w = 0; w < RED_THREADS / WAVE; ++w)
+            for (int k = 0; k < 3; ++k) t[k] += s_acc[k][w];
+        const double cls = t[0], dist = t[1], npos = t[2];
         out[0] = (float)(npos != 0.0 ? dist / npos : dist);
         out[1] = (float)(npos != 0.0 ? cls / npos : cls);
         out[2] = (float)npos;
@@ -664,18 +758,23 @@ int odbox_match_loss(const float *anchors, const float *gt_boxes, const int32_t 
     const uint32_t magic = d == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / d);
     const LossParams lp = {gamma, alpha, huber_delta};
     hipStream_t st = (hipStream_t)stream;
-    if (grad_scores)
-        hipLaunchKernelGGL(match_loss_kernel<true>, dim3((uint32_t)blocks), dim3(ME_TILE), 0, st, (const float4 *)anchors,
+    const bool g15 = gamma == 1.5f;                 // the reference's default: pow as x * sqrt(x)
+    const bool al = (d & 3u) == 0 && aligned16(pred_scores);
+    auto launch = [&](auto kernel, float4 *gb, float *gs) {
+        hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(ME_TILE), 0, st, (const float4 *)anchors,
                            (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w, neg_thr, pos_thr,
-                           (const float4 *)pred_boxes, pred_scores, lp, (float4 *)grad_boxes, grad_scores,
-                           (float *)workspace, (uint32_t)tiles, magic);
-    else
-        hipLaunchKernelGGL(match_loss_kernel<false>, dim3((uint32_t)blocks), dim3(ME_TILE), 0, st, (const float4 *)anchors,
-                           (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w, neg_thr, pos_thr,
-                           (const float4 *)pred_boxes, pred_scores, lp, (float4 *)nullptr, (float *)nullptr,
-                           (float *)workspace, (uint32_t)tiles, magic);
+                           (const float4 *)pred_boxes, pred_scores, lp, gb, gs, (float *)workspace, (uint32_t)tiles,
+                           magic);
+    };
+    auto pick = [&](auto grads, float4 *gb, float *gs) {
+        constexpr bool GR = decltype(grads)::value;
+        if (g15) { if (al) launch(match_loss_kernel<GR, true, true>, gb, gs); else launch(match_loss_kernel<GR, true, false>, gb, gs); }
+        else     { if (al) launch(match_loss_kernel<GR, false, true>, gb, gs); else launch(match_loss_kernel<GR, false, false>, gb, gs); }
+    };
+    if (grad_scores) pick(std::true_type{}, (float4 *)grad_boxes, grad_scores);
+    else pick(std::false_type{}, (float4 *)nullptr, (float *)nullptr);
     if (int rc = launch_status("match_loss")) return rc;
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, (const float *)workspace, (uint32_t)blocks, out_loss);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, st, (const float *)workspace, (uint32_t)blocks, out_loss);
     return launch_status("loss_reduce");
 }
 
@@ -700,12 +799,16 @@ int odbox_focal_loss(const float *y_true, const float *y_pred, size_t n, float g
     if (blocks < 1) blocks = 1;
     const LossParams lp = {gamma, alpha, 1.0f};
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(focal_dense_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, y_true, y_pred, n, lp, grad,
-                       (float *)workspace);
+    if (gamma == 1.5f)
+        hipLaunchKernelGGL(focal_dense_kernel<true>, dim3((uint32_t)blocks), dim3(256), 0, st, y_true, y_pred, n, lp, grad,
+                           (float *)workspace);
+    else
+        hipLaunchKernelGGL(focal_dense_kernel<false>, dim3((uint32_t)blocks), dim3(256), 0, st, y_true, y_pred, n, lp, grad,
+                           (float *)workspace);
     if (int rc = launch_status("focal_dense")) return rc;
     // reuse the 3-slot reducer: slot 0 holds the sum, npos slot is 0 so nothing is divided; the
     // sum comes out in out[1]; out_sum must therefore have room for 4 floats
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, (const float *)workspace, (uint32_t)blocks, out_sum);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, st, (const float *)workspace, (uint32_t)blocks, out_sum);
     return launch_status("loss_reduce");
 }
 
