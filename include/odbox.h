@@ -34,6 +34,9 @@ extern "C" {
 #define ODBOX_MAX_CLASSES   4096     /* class id is 12 bits of the candidate key */
 #define ODBOX_MAX_ANCHORS   1048576  /* anchor id is 20 bits of the candidate key */
 #define ODBOX_MAX_RET       4096     /* kept list of one (image, class) lives in LDS */
+#define ODBOX_COCO_MAX_THRS  16      /* IoU thresholds of one odbox_coco_match call */
+#define ODBOX_COCO_MAX_AREAS 8       /* area ranges of one odbox_coco_match call */
+#define ODBOX_COCO_MAX_GT    1024    /* GT rows per image held in registers by the matcher */
 
 int odbox_version(void);
 const char *odbox_last_error(void);
@@ -125,6 +128,43 @@ int odbox_decode_nms(const float *anchors /*[N,4] or NULL*/, const float *regres
                      float *out_boxes /*[B,max_ret,4]*/, float *out_scores /*[B,max_ret]*/,
                      int32_t *out_labels /*[B,max_ret]*/, int32_t *out_keep_anchor /*[B,max_ret]*/,
                      int32_t *out_count /*[B]*/, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- evaluation side: the step after the all-gather of detections ---- */
+
+/* evaluate.py:14-28 _COCO_result / :31-55 _COCO_gt_annot: xyxy -> (x, y, w, h) with fp32 w = x1-x0,
+ * h = y1-y0; out_area_f32 = h*w in fp32 (the GT annotation's 'area', :41); out_area_f64 =
+ * (double)w*(double)h (the detection's 'area', :177).  Any output may be NULL. */
+int odbox_coco_records(const float *boxes /*[n,4] xyxy*/, size_t n, float *out_xywh /*[n,4]*/,
+                       float *out_area_f32 /*[n]*/, double *out_area_f64 /*[n]*/, void *stream);
+
+/* cocoeval.py:167-194 computeIoU = pycocotools maskUtils.iou on boxes (bbIou, iscrowd = 0), in
+ * fp64 like the C original: out[b,d,g] for every detection slot d and GT row g of image b.
+ * self.ious[img, cat] is the sub-matrix of the category's rows / slots in score order. */
+int odbox_coco_iou(const float *dt_boxes /*[B,R,4] xyxy*/, const float *gt_boxes /*[B,G,4] xyxy*/,
+                   int B, int R, int G, double *out_iou /*[B,R,G]*/, void *stream);
+
+/* cocoeval.py:239-317 evaluateImg for every (image, category, area range, IoU threshold) at once,
+ * with _prepare (:88-123) and evaluate.py:93-110 folded in: GT rows with label -1 are padding and
+ * dropped; detection rows are NOT filtered (zero-score padding rows are category-0 detections,
+ * like the reference feeds them); rows / slots whose label is outside [0, C) are not evaluated.
+ * Each (image, category) detection list is ordered by (score desc, slot asc) = the reference's
+ * stable mergesort, cut at max_det (= maxDets[-1]).
+ *   out_dt_match  [B,A,T,R] int32  1 + matched GT row (index into the image's G rows), 0 = none
+ *   out_dt_ignore [B,A,T,R] uint8  dtIgnore
+ *   out_gt_match  [B,A,T,G] int32  1 + matched detection slot, 0 = none          (may be NULL)
+ *   out_gt_ignore [B,A,G]   uint8  0 counted / 1 ignored (area range) / 255 absent (may be NULL)
+ *   out_dt_rank   [B,R]     int32  position in its (image, category) list, -1 = not evaluated
+ * iou_thrs_h [T] and area_rng_h [A,2] are HOST arrays of doubles (cocoeval.py:510-513).
+ * COCO ids follow from the indices: detection id = 1 + b*R + slot (evaluate.py:178); GT id =
+ * 1 + number of kept GT rows before it (evaluate.py:53,141). */
+size_t odbox_coco_match_workspace(int B, int R);
+int odbox_coco_match(const float *dt_boxes /*[B,R,4]*/, const float *dt_scores /*[B,R]*/,
+                     const int32_t *dt_labels /*[B,R]*/, const float *gt_boxes /*[B,G,4]*/,
+                     const int32_t *gt_labels /*[B,G]*/, int B, int R, int G, int C,
+                     const double *iou_thrs_h /*[T]*/, int T, const double *area_rng_h /*[A,2]*/, int A,
+                     int max_det, int32_t *out_dt_match, uint8_t *out_dt_ignore, int32_t *out_gt_match,
+                     uint8_t *out_gt_ignore, int32_t *out_dt_rank, void *workspace, size_t workspace_bytes,
+                     void *stream);
 
 #ifdef __cplusplus
 }

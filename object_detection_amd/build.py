@@ -19,6 +19,7 @@ COMMON = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-std=c+
 UNITS = {
     'odbox_train.hip': [],
     'odbox_infer.hip': ['-fno-honor-nans'],
+    'odbox_eval.hip': [],
 }
 HEADERS = [os.path.join(CSRC, 'odbox_common.h'), os.path.join(ROOT, 'include', 'odbox.h')]
 

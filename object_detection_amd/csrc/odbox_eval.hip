@@ -1,0 +1,356 @@
+// odbox_eval.hip -- evaluation side of the box path: the step right after the
+// all-gather of detections.  evaluate.py:14-55,93-110,172-181 (tensors -> COCO xywh records and
+// areas), cocoeval.py:167-194 (computeIoU through pycocotools' bbIou) and cocoeval.py:239-317
+// (evaluateImg: greedy matching per image, category, area range and IoU threshold), on device
+// tensors instead of Python lists of dicts.
+//
+// Numerical contract: bbIou works on C doubles made from fp32 values (the reference hands
+// `.numpy().tolist()` lists to pycocotools), so everything here is IEEE fp64 with the same
+// association and no contraction (-ffp-contract=off): match tables are bit-exact, IoUs too.
+#include "odbox_common.h"
+
+using namespace odbox;
+
+namespace {
+
+// pycocotools maskApi.c bbIou for one (detection, ground truth) pair, iscrowd = 0 (evaluate.py:52
+// never sets it).  Boxes are (x, y, w, h) with w, h the fp32 differences of evaluate.py:19-20.
+__device__ __forceinline__ double bb_iou(float dx, float dy, float dw, float dh, float gx, float gy, float gw,
+                                         float gh)
+{
+    const double Dx = dx, Dy = dy, Dw = dw, Dh = dh, Gx = gx, Gy = gy, Gw = gw, Gh = gh;
+    const double w = fmin(Dw + Dx, Gw + Gx) - fmax(Dx, Gx);
+    if (w <= 0.0) return 0.0;
+    const double h = fmin(Dh + Dy, Gh + Gy) - fmax(Dy, Gy);
+    if (h <= 0.0) return 0.0;
+    const double i = w * h;
+    const double u = (Dw * Dh + Gw * Gh) - i;
+    return i / u;
+}
+
+// evaluate.py:19-22 / :39-45: xyxy -> (x, y, w, h); :41 fp32 area of a GT box; :177 double area of
+// a detection (product of the two widened fp32 sides, exact).
+__global__ __launch_bounds__(256) void coco_records_kernel(const float4 *__restrict__ boxes, size_t n,
+                                                           float4 *__restrict__ xywh, float *__restrict__ area32,
+                                                           double *__restrict__ area64)
+{
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 b = boxes[i];
+    const float h = b.w - b.y, w = b.z - b.x;
+    if (xywh) xywh[i] = make_float4(b.x, b.y, w, h);
+    if (area32) area32[i] = h * w;
+    if (area64) area64[i] = (double)w * (double)h;
+}
+
+// cocoeval.py:167-194 without the per-category regrouping: out[b, d, g] for every detection slot d
+// and GT row g of image b (the caller slices by category / score order; padded rows give 0).
+__global__ __launch_bounds__(256) void coco_iou_kernel(const float4 *__restrict__ dt, const float4 *__restrict__ gt,
+                                                       int R, int G, double *__restrict__ out, size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= total) return;
+    const size_t bd = i / (size_t)G;
+    const uint32_t g = (uint32_t)(i - bd * (size_t)G);
+    const size_t b = bd / (size_t)R;
+    const float4 D = dt[bd], Gb = gt[b * (size_t)G + g];
+    out[i] = bb_iou(D.x, D.y, D.z - D.x, D.w - D.y, Gb.x, Gb.y, Gb.z - Gb.x, Gb.w - Gb.y);
+}
+
+// Per image: the evaluation order of its detections.  cocoeval.py:100-101 keeps a detection only if
+// its category is known; :177-180 / :263-264 sort every (image, category) list by score with a
+// stable mergesort (ties keep slot order) and cut it at maxDets[-1].  Categories never interact, so
+// one list per image in (score desc, slot asc) order visits every category's list in its own order.
+//   order[b, 0..count[b])  slots of the evaluated detections in that order
+//   rank[b, slot]          position inside its (image, category) list, -1 = not evaluated
+constexpr int ORDER_THREADS = 256;
+__global__ __launch_bounds__(ORDER_THREADS) void coco_order_kernel(const float *__restrict__ scores,
+                                                                   const int32_t *__restrict__ labels, int R, int C,
+                                                                   int max_det, int32_t *__restrict__ order,
+                                                                   int32_t *__restrict__ count,
+                                                                   int32_t *__restrict__ rank)
+{
+    extern __shared__ unsigned char smem[];
+    float *s_score = reinterpret_cast<float *>(smem);
+    int32_t *s_label = reinterpret_cast<int32_t *>(smem) + R;          // label, or -1: unknown category
+    uint8_t *s_keep = smem + (size_t)R * 8;                             // 1: evaluated
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const float *sc = scores + (size_t)b * R;
+    const int32_t *lb = labels + (size_t)b * R;
+    for (int i = tid; i < R; i += ORDER_THREADS) {
+        const int32_t l = lb[i];
+        s_score[i] = sc[i];
+        s_label[i] = (l >= 0 && l < C) ? l : -1;
+    }
+    __syncthreads();
+    // pass 1: rank inside the category (every detection of the category counts, kept or not)
+    for (int i = tid; i < R; i += ORDER_THREADS) {
+        int r = -1;
+        const int32_t l = s_label[i];
+        if (l >= 0) {
+            const float s = s_score[i];
+            r = 0;
+            for (int j = 0; j < R; ++j) {
+                const float sj = s_score[j];
+                r += (s_label[j] == l && (sj > s || (sj == s && j < i))) ? 1 : 0;
+            }
+            if (r >= max_det) r = -1;
+        }
+        rank[(size_t)b * R + i] = r;
+        s_keep[i] = r >= 0 ? 1 : 0;
+    }
+    __syncthreads();
+    // pass 2: position among the evaluated detections of the image
+    for (int i = tid; i < R; i += ORDER_THREADS) {
+        if (!s_keep[i]) continue;
+        const float s = s_score[i];
+        int pos = 0;
+        for (int j = 0; j < R; ++j) {
+            const float sj = s_score[j];
+            pos += (s_keep[j] && (sj > s || (sj == s && j < i))) ? 1 : 0;
+        }
+        order[(size_t)b * R + pos] = i;
+    }
+    if (tid == 0) {
+        int n_eval = 0;
+        for (int j = 0; j < R; ++j) n_eval += s_keep[j];
+        count[b] = n_eval;
+    }
+}
+
+constexpr int COCO_MAX_T = ODBOX_COCO_MAX_THRS;
+constexpr int COCO_MAX_A = ODBOX_COCO_MAX_AREAS;
+struct CocoParams {
+    int T, A, C;
+    double thr[COCO_MAX_T];
+    double lo[COCO_MAX_A], hi[COCO_MAX_A];
+};
+
+__device__ __forceinline__ float lane_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+// cocoeval.py:239-317 evaluateImg.  One wave per (image, area range, IoU threshold); lane = GT row
+// (KG rows per lane), detections visited in the order list.  The reference's inner loop over the
+// GTs sorted "ignored last" keeps the best IoU >= min(t, 1 - 1e-10) among the still unmatched
+// rows of the detection's category, the LAST one on ties, and never looks at ignored rows once a
+// counted row matched: that is "max over counted rows, else max over ignored rows, ties to the
+// higher row", a wave reduction.
+template <int KG>
+__global__ __launch_bounds__(WAVE) void coco_match_kernel(
+    const float4 *__restrict__ dt_boxes, const int32_t *__restrict__ dt_labels, const int32_t *__restrict__ order,
+    const int32_t *__restrict__ count, const int32_t *__restrict__ rank, const float4 *__restrict__ gt_boxes,
+    const int32_t *__restrict__ gt_labels, int R, int G, CocoParams P, int32_t *__restrict__ out_dt_match,
+    uint8_t *__restrict__ out_dt_ignore, int32_t *__restrict__ out_gt_match, uint8_t *__restrict__ out_gt_ignore)
+{
+    const int lane = (int)threadIdx.x;
+    const uint32_t at = (uint32_t)(P.A * P.T);
+    const uint32_t b = blockIdx.x / at;
+    const uint32_t rem = blockIdx.x - b * at;
+    const uint32_t a = rem / (uint32_t)P.T, t = rem - a * (uint32_t)P.T;
+    const double lo = P.lo[a], hi = P.hi[a];
+    const double thr0 = fmin(P.thr[t], 1.0 - 1e-10);                      // cocoeval.py:280
+
+    float gx[KG], gy[KG], gw[KG], gh[KG];
+    int glab[KG], gig[KG], gm[KG];
+#pragma unroll
+    for (int c = 0; c < KG; ++c) {
+        const int g = c * WAVE + lane;
+        glab[c] = -1;
+        gig[c] = 0;
+        gm[c] = 0;
+        gx[c] = gy[c] = gw[c] = gh[c] = 0.0f;
+        if (g < G) {
+            const int32_t l = gt_labels[(size_t)b * G + g];
+            const float4 bx = gt_boxes[(size_t)b * G + g];
+            gx[c] = bx.x;
+            gy[c] = bx.y;
+            gw[c] = bx.z - bx.x;                                          // evaluate.py:40
+            gh[c] = bx.w - bx.y;                                          // :39
+            const double area = (double)(gh[c] * gw[c]);                  // :41 fp32 product, widened
+            if (l >= 0 && l < P.C) {
+                glab[c] = l;
+                gig[c] = (area < lo || area > hi) ? 1 : 0;                // cocoeval.py:255
+            }
+            if (t == 0 && out_gt_ignore)
+                out_gt_ignore[((size_t)b * P.A + a) * G + g] = glab[c] < 0 ? (uint8_t)255 : (uint8_t)gig[c];
+        }
+    }
+
+    const size_t dt_out = (((size_t)b * P.A + a) * P.T + t) * (size_t)R;
+    const int n = count[b];
+    for (int j0 = 0; j0 < n; j0 += WAVE) {
+        const int my = j0 + lane;
+        const int slot = my < n ? order[(size_t)b * R + my] : -1;
+        float4 db = make_float4(0.f, 0.f, 0.f, 0.f);
+        int dlab = -2;
+        if (slot >= 0) {
+            db = dt_boxes[(size_t)b * R + slot];
+            dlab = dt_labels[(size_t)b * R + slot];
+        }
+        const float dw = db.z - db.x, dh = db.w - db.y;                   // evaluate.py:19-20
+        const double darea = (double)dw * (double)dh;                     // :177
+        int res_m = 0;
+        int res_ig = (darea < lo || darea > hi) ? 1 : 0;                  // cocoeval.py:302-303 (if unmatched)
+        const int cnt = min(WAVE, n - j0);
+        for (int j = 0; j < cnt; ++j) {
+            const int lab = __builtin_amdgcn_readlane(dlab, j);
+            bool any = false;
+#pragma unroll
+            for (int c = 0; c < KG; ++c) any = any || (glab[c] == lab && gm[c] == 0);
+            if (__ballot(any) == 0ull) continue;
+            const float x = lane_f(db.x, j), y = lane_f(db.y, j), w = lane_f(dw, j), h = lane_f(dh, j);
+            double bi0 = -1.0, bi1 = -1.0;
+            int bg0 = -1, bg1 = -1;
+#pragma unroll
+            for (int c = 0; c < KG; ++c) {
+                if (glab[c] == lab && gm[c] == 0) {
+                    const double iou = bb_iou(x, y, w, h, gx[c], gy[c], gw[c], gh[c]);
+                    if (iou >= thr0) {
+                        if (gig[c]) {
+                            if (iou >= bi1) { bi1 = iou; bg1 = c * WAVE + lane; }
+                        } else {
+                            if (iou >= bi0) { bi0 = iou; bg0 = c * WAVE + lane; }
+                        }
+                    }
+                }
+            }
+            const bool use1 = __ballot(bg0 >= 0) == 0ull;                 // no counted row matched: try ignored rows
+            const double bi = use1 ? bi1 : bi0;
+            const int bg = use1 ? bg1 : bg0;
+            const unsigned long long mm = __ballot(bg >= 0);
+            if (mm == 0ull) continue;
+            int win;
+            if (__popcll(mm) == 1) {
+                win = __ffsll(mm) - 1;
+            } else {
+                double mx = bi;
+#pragma unroll
+                for (int off = 1; off < WAVE; off <<= 1) mx = fmax(mx, __shfl_xor(mx, off));
+                int gs = (bg >= 0 && bi == mx) ? bg : -1;
+#pragma unroll
+                for (int off = 1; off < WAVE; off <<= 1) gs = max(gs, __shfl_xor(gs, off));
+                win = __builtin_amdgcn_readfirstlane(gs) & (WAVE - 1);
+            }
+            const int wg = __builtin_amdgcn_readlane(bg, win);
+            const int dslot = __builtin_amdgcn_readlane(slot, j);
+#pragma unroll
+            for (int c = 0; c < KG; ++c)
+                if (lane == win && c == (wg >> 6)) gm[c] = dslot + 1;     // cocoeval.py:300
+            if (lane == j) {
+                res_m = wg + 1;                                           // :299
+                res_ig = use1 ? 1 : 0;                                    // :298
+            }
+        }
+        if (slot >= 0) {
+            out_dt_match[dt_out + slot] = res_m;
+            out_dt_ignore[dt_out + slot] = (uint8_t)res_ig;
+        }
+    }
+    for (int s = lane; s < R; s += WAVE)
+        if (rank[(size_t)b * R + s] < 0) {
+            out_dt_match[dt_out + s] = 0;
+            out_dt_ignore[dt_out + s] = 0;
+        }
+    if (out_gt_match) {
+        const size_t gt_out = (((size_t)b * P.A + a) * P.T + t) * (size_t)G;
+#pragma unroll
+        for (int c = 0; c < KG; ++c) {
+            const int g = c * WAVE + lane;
+            if (g < G) out_gt_match[gt_out + g] = gm[c];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int odbox_coco_records(const float *boxes, size_t n, float *out_xywh, float *out_area_f32, double *out_area_f64,
+                       void *stream)
+{
+    if (n == 0) return 0;
+    if (!boxes) return fail(ODBOX_EINVAL, "odbox_coco_records: NULL boxes");
+    if (!aligned16(boxes) || (out_xywh && !aligned16(out_xywh)))
+        return fail(ODBOX_EINVAL, "odbox_coco_records: box tensors must be 16-byte aligned");
+    const size_t blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_coco_records: too many boxes");
+    hipLaunchKernelGGL(coco_records_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)boxes, n, (float4 *)out_xywh, out_area_f32, out_area_f64);
+    return launch_status("coco_records");
+}
+
+int odbox_coco_iou(const float *dt_boxes, const float *gt_boxes, int B, int R, int G, double *out_iou, void *stream)
+{
+    if (B < 0 || R < 0 || G < 0) return fail(ODBOX_EINVAL, "odbox_coco_iou: negative shape");
+    if (B == 0 || R == 0 || G == 0) return 0;
+    if (!dt_boxes || !gt_boxes || !out_iou) return fail(ODBOX_EINVAL, "odbox_coco_iou: NULL pointer");
+    if (!aligned16(dt_boxes) || !aligned16(gt_boxes))
+        return fail(ODBOX_EINVAL, "odbox_coco_iou: box tensors must be 16-byte aligned");
+    const size_t total = (size_t)B * R * G;
+    const size_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_coco_iou: grid too large");
+    hipLaunchKernelGGL(coco_iou_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)dt_boxes, (const float4 *)gt_boxes, R, G, out_iou, total);
+    return launch_status("coco_iou");
+}
+
+size_t odbox_coco_match_workspace(int B, int R)
+{
+    if (B < 1 || R < 1) return 0;
+    return (((size_t)B * R + (size_t)B) * sizeof(int32_t) + 255) / 256 * 256;
+}
+
+int odbox_coco_match(const float *dt_boxes, const float *dt_scores, const int32_t *dt_labels, const float *gt_boxes,
+                     const int32_t *gt_labels, int B, int R, int G, int C, const double *iou_thrs_h, int T,
+                     const double *area_rng_h, int A, int max_det, int32_t *out_dt_match, uint8_t *out_dt_ignore,
+                     int32_t *out_gt_match, uint8_t *out_gt_ignore, int32_t *out_dt_rank, void *workspace,
+                     size_t workspace_bytes, void *stream)
+{
+    if (B < 0 || R < 0 || G < 0 || C < 1 || max_det < 1)
+        return fail(ODBOX_EINVAL, "odbox_coco_match: bad shape B=%d R=%d G=%d C=%d max_det=%d", B, R, G, C, max_det);
+    if (T < 1 || T > COCO_MAX_T || A < 1 || A > COCO_MAX_A || !iou_thrs_h || !area_rng_h)
+        return fail(ODBOX_EINVAL, "odbox_coco_match: need 1..%d IoU thresholds and 1..%d area ranges (host arrays)",
+                    COCO_MAX_T, COCO_MAX_A);
+    if (R > ODBOX_MAX_RET) return fail(ODBOX_EINVAL, "odbox_coco_match: R=%d exceeds %d", R, ODBOX_MAX_RET);
+    if (G > ODBOX_COCO_MAX_GT) return fail(ODBOX_EINVAL, "odbox_coco_match: G=%d exceeds %d", G, ODBOX_COCO_MAX_GT);
+    if (B == 0 || R == 0) return 0;
+    if (!dt_boxes || !dt_scores || !dt_labels || !out_dt_match || !out_dt_ignore || !out_dt_rank)
+        return fail(ODBOX_EINVAL, "odbox_coco_match: NULL pointer");
+    if (G > 0 && (!gt_boxes || !gt_labels)) return fail(ODBOX_EINVAL, "odbox_coco_match: NULL ground truth");
+    if (!aligned16(dt_boxes) || (G > 0 && !aligned16(gt_boxes)))
+        return fail(ODBOX_EINVAL, "odbox_coco_match: box tensors must be 16-byte aligned");
+    const size_t need = odbox_coco_match_workspace(B, R);
+    if (!workspace || workspace_bytes < need)
+        return fail(ODBOX_ENOSPC, "odbox_coco_match: workspace %zu bytes, need %zu", workspace_bytes, need);
+    const uint64_t waves = (uint64_t)B * (uint64_t)A * (uint64_t)T;
+    if (waves > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_coco_match: grid too large");
+
+    CocoParams P;
+    P.T = T;
+    P.A = A;
+    P.C = C;
+    for (int i = 0; i < COCO_MAX_T; ++i) P.thr[i] = i < T ? iou_thrs_h[i] : 2.0;
+    for (int i = 0; i < COCO_MAX_A; ++i) {
+        P.lo[i] = i < A ? area_rng_h[2 * i] : 0.0;
+        P.hi[i] = i < A ? area_rng_h[2 * i + 1] : 0.0;
+    }
+    int32_t *order = (int32_t *)workspace;
+    int32_t *count = order + (size_t)B * R;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(coco_order_kernel, dim3((uint32_t)B), dim3(ORDER_THREADS), (size_t)R * 9, st, dt_scores, dt_labels,
+                       R, C, max_det, order, count, out_dt_rank);
+    if (int rc = launch_status("coco_order")) return rc;
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((uint32_t)waves), dim3(WAVE), 0, st, (const float4 *)dt_boxes, dt_labels,
+                           (const int32_t *)order, (const int32_t *)count, (const int32_t *)out_dt_rank,
+                           (const float4 *)gt_boxes, gt_labels, R, G, P, out_dt_match, out_dt_ignore, out_gt_match,
+                           out_gt_ignore);
+    };
+    if (G <= 64) launch(coco_match_kernel<1>);
+    else if (G <= 128) launch(coco_match_kernel<2>);
+    else if (G <= 256) launch(coco_match_kernel<4>);
+    else if (G <= 512) launch(coco_match_kernel<8>);
+    else launch(coco_match_kernel<16>);
+    return launch_status("coco_match");
+}
+
+}  // extern "C"

@@ -105,3 +105,40 @@ def nms_inputs(N, C=90, batch=64, seed=1005, clusters=50, p3p4_anchors=None, dis
     reg = np.tile(reg, (reps, 1, 1))[:batch]
     sc = np.tile(sc, (reps, 1, 1))[:batch]
     return reg, sc
+
+
+def eval_inputs(B=64, R=100, G=64, C=80, S=512, seed=1006, valid_gt=20, few_classes=None):
+    """Evaluation-side batch: padded GT `[B,G,4]` / `[B,G]` (valid_gt real rows,
+    the rest -1) and padded, score-sorted detections `[B,R,4]`, `[B,R]`, `[B,R]` shaped like the
+    output of decode+NMS: jittered copies of GT rows (some twice, so duplicates compete for one
+    GT), false positives, exact score ties (scores on a 2^-7 grid), then zero rows.
+    few_classes: draw labels from that many classes only (forces several GT per category)."""
+    rng = np.random.default_rng(seed)
+    cls = C if few_classes is None else few_classes
+    gt_b = np.full((B, G, 4), -1, np.float32)
+    gt_l = np.full((B, G), -1, np.int32)
+    dt_b = np.zeros((B, R, 4), np.float32)
+    dt_s = np.zeros((B, R), np.float32)
+    dt_l = np.zeros((B, R), np.int32)
+    for b in range(B):
+        nv = min(valid_gt, G)
+        boxes, _ = gt_boxes(rng, S, nv, C)
+        labels = rng.integers(0, cls, size=nv).astype(np.int32)
+        gt_b[b, :nv] = boxes
+        gt_l[b, :nv] = labels
+        n_det = int(rng.integers(R // 2, R + 1)) if nv else 0
+        rows = []
+        for _ in range(n_det):
+            if nv and rng.random() < 0.7:
+                g = int(rng.integers(0, nv))
+                jit = rng.normal(0, 0.08, size=4) * np.tile(boxes[g, 2:] - boxes[g, :2], 2)
+                box = boxes[g] + jit.astype(np.float32)
+                lab = labels[g] if rng.random() < 0.9 else rng.integers(0, cls)
+            else:
+                box, lab = gt_boxes(rng, S, 1, C)[0][0], rng.integers(0, cls)
+            box = np.array([min(box[0], box[2]), min(box[1], box[3]), max(box[0], box[2]), max(box[1], box[3])])
+            rows.append((np.round(rng.uniform(0.3, 1.0) * 128) / 128, box, lab))
+        rows.sort(key=lambda r: -r[0])
+        for k, (s, box, lab) in enumerate(rows):
+            dt_s[b, k], dt_b[b, k], dt_l[b, k] = s, box, lab
+    return dict(dt_boxes=dt_b, dt_scores=dt_s, dt_labels=dt_l, gt_boxes=gt_b, gt_labels=gt_l)
