@@ -166,6 +166,29 @@ int odbox_coco_match(const float *dt_boxes /*[B,R,4]*/, const float *dt_scores /
                      uint8_t *out_gt_ignore, int32_t *out_dt_rank, void *workspace, size_t workspace_bytes,
                      void *stream);
 
+/* ---- ground-truth preparation: the step that feeds the matcher ---- */
+
+/* detection.py:97-141 prepare_example (box arithmetic of the evaluation path) + :257-262
+ * padded_batch.  Images are ragged: image b owns rows row_offsets[b] .. row_offsets[b+1] of
+ * boxes_xywh / labels (device int32 [B+1]).  Per row: x0 += (max(H,W) - W)/2, y0 += (max(H,W) - H)/2
+ * (square pad), 4 corners, each coordinate / max(H,W) * image_size, optional round to fp16
+ * (half_round != 0: the mixed-precision input pipeline), polygon2bbox (:77-95), rows beyond
+ * max_items cut, missing rows = -1 boxes / -1 labels.  mode 0 = (xmin,ymin,xmax,ymax),
+ * 1 = want_yx, 2 = want_wh.  orig_hw [B,2] = (height, width) of the original image as floats. */
+int odbox_gt_prepare_xywh(const float *boxes_xywh /*[rows,4]*/, const int32_t *labels /*[rows]*/,
+                          const int32_t *row_offsets /*[B+1]*/, const float *orig_hw /*[B,2]*/, int B,
+                          int max_items, float image_size, int half_round, int mode,
+                          float *out_boxes /*[B,max_items,4]*/, int32_t *out_labels /*[B,max_items]*/,
+                          void *stream);
+
+/* The same from corner polygons [rows,4,2] on a square canvas of side canvas_size[b] (what the
+ * training augmentation hands back, detection.py:126,131-141). */
+int odbox_gt_prepare_poly(const float *polys /*[rows,4,2]*/, const int32_t *labels /*[rows]*/,
+                          const int32_t *row_offsets /*[B+1]*/, const float *canvas_size /*[B]*/, int B,
+                          int max_items, float image_size, int half_round, int mode,
+                          float *out_boxes /*[B,max_items,4]*/, int32_t *out_labels /*[B,max_items]*/,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

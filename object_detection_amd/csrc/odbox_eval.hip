@@ -8,6 +8,7 @@
 // `.numpy().tolist()` lists to pycocotools), so everything here is IEEE fp64 with the same
 // association and no contraction (-ffp-contract=off): match tables are bit-exact, IoUs too.
 #include "odbox_common.h"
+#include <hip/hip_fp16.h>
 
 using namespace odbox;
 
@@ -351,6 +352,136 @@ int odbox_coco_match(const float *dt_boxes, const float *dt_scores, const int32_
     else if (G <= 512) launch(coco_match_kernel<8>);
     else launch(coco_match_kernel<16>);
     return launch_status("coco_match");
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// ground-truth preparation, the step that feeds the matcher.
+// detection.py:97-141 (prepare_example, the box arithmetic of the evaluation path: square-pad
+// offset, corner polygon, rescale to the network input size, cast, polygon2bbox :77-95, cut at
+// max_items_in_image) and :257-262 (padded_batch: rows beyond an image's count are -1).
+// Images arrive ragged (CSR row offsets), leave as the dense [B, max_items, 4] / [B, max_items]
+// tensors the matcher reads.  One thread per output row.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ float round_half(float v) { return __half2float(__float2half_rn(v)); }
+
+// polygon2bbox over the 4 corners, in the tensor's dtype (fp16 values stay exactly representable
+// through min/max; want_wh subtracts in that dtype too)
+template <bool HALF>
+__device__ __forceinline__ float4 poly_bbox(const float px[4], const float py[4], int mode)
+{
+    const float xmin = fminf(fminf(px[0], px[1]), fminf(px[2], px[3]));
+    const float ymin = fminf(fminf(py[0], py[1]), fminf(py[2], py[3]));
+    const float xmax = fmaxf(fmaxf(px[0], px[1]), fmaxf(px[2], px[3]));
+    const float ymax = fmaxf(fmaxf(py[0], py[1]), fmaxf(py[2], py[3]));
+    if (mode == 1) return make_float4(ymin, xmin, ymax, xmax);                          // want_yx
+    if (mode == 2) {                                                                     // want_wh
+        if (HALF)
+            return make_float4(xmin, ymin, __half2float(__hsub(__float2half_rn(xmax), __float2half_rn(xmin))),
+                               __half2float(__hsub(__float2half_rn(ymax), __float2half_rn(ymin))));
+        return make_float4(xmin, ymin, xmax - xmin, ymax - ymin);
+    }
+    return make_float4(xmin, ymin, xmax, ymax);
+}
+
+// FROM_XYWH: boxes are the dataset's (x0, y0, w, h) in original pixels and sizes[b] = (height, width)
+// of the original image (detection.py:98-123, :131 with the evaluation path's unchanged canvas).
+// else: boxes are [rows, 4, 2] corner polygons on a canvas of side sizes[b] (the output of the
+// training augmentation, detection.py:126,131).
+template <bool FROM_XYWH, bool HALF>
+__global__ __launch_bounds__(256) void gt_prepare_kernel(const float *__restrict__ src, const int32_t *__restrict__ labels,
+                                                         const int32_t *__restrict__ row_offsets,
+                                                         const float *__restrict__ sizes, int B, int max_items,
+                                                         float image_size, int mode, float4 *__restrict__ out_boxes,
+                                                         int32_t *__restrict__ out_labels)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (uint32_t)B * (uint32_t)max_items) return;
+    const uint32_t b = i / (uint32_t)max_items, k = i - b * (uint32_t)max_items;
+    const int32_t r0 = row_offsets[b], r1 = row_offsets[b + 1];
+    float4 box = make_float4(-1.f, -1.f, -1.f, -1.f);                    // padding_values -1 (:262)
+    int32_t lab = -1;
+    if ((int32_t)k < r1 - r0) {                                           // rows past max_items are cut (:140-141)
+        const size_t r = (size_t)r0 + k;
+        float px[4], py[4], cur;
+        if (FROM_XYWH) {
+            const float4 s = reinterpret_cast<const float4 *>(src)[r];
+            const float H = sizes[2 * b], W = sizes[2 * b + 1];
+            const float mx = fmaxf(H, W);                                 // :103
+            const float x0 = s.x + (mx - W) / 2.0f;                      // :110
+            const float y0 = s.y + (mx - H) / 2.0f;                      // :111
+            px[0] = x0;       py[0] = y0;                                 // :118-121
+            px[1] = x0 + s.z; py[1] = y0;
+            px[2] = x0 + s.z; py[2] = y0 + s.w;
+            px[3] = x0;       py[3] = y0 + s.w;
+            cur = (float)(int)mx;                                         // :104-109,131: side of the padded canvas
+        } else {
+            const float4 a = reinterpret_cast<const float4 *>(src)[2 * r], c = reinterpret_cast<const float4 *>(src)[2 * r + 1];
+            px[0] = a.x; py[0] = a.y; px[1] = a.z; py[1] = a.w;
+            px[2] = c.x; py[2] = c.y; px[3] = c.z; py[3] = c.w;
+            cur = sizes[b];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            px[q] = (px[q] / cur) * image_size;                           // :135
+            py[q] = (py[q] / cur) * image_size;
+            if (HALF) {                                                   // :136 cast to the image dtype
+                px[q] = round_half(px[q]);
+                py[q] = round_half(py[q]);
+            }
+        }
+        box = poly_bbox<HALF>(px, py, mode);                              // :138
+        lab = labels[r];
+    }
+    out_boxes[i] = box;
+    out_labels[i] = lab;
+}
+
+int gt_prepare(const char *name, bool from_xywh, const float *src, const int32_t *labels, const int32_t *row_offsets,
+               const float *sizes, int B, int max_items, float image_size, int half_round, int mode, float *out_boxes,
+               int32_t *out_labels, void *stream)
+{
+    if (B < 0 || max_items < 0) return fail(ODBOX_EINVAL, "%s: negative shape", name);
+    if (B == 0 || max_items == 0) return 0;
+    if (!row_offsets || !sizes || !out_boxes || !out_labels) return fail(ODBOX_EINVAL, "%s: NULL pointer", name);
+    if (mode < 0 || mode > 2) return fail(ODBOX_EINVAL, "%s: mode must be 0 (xyxy), 1 (yxyx) or 2 (xywh)", name);
+    if ((src && !aligned16(src)) || !aligned16(out_boxes))
+        return fail(ODBOX_EINVAL, "%s: box tensors must be 16-byte aligned", name);
+    if (!(image_size > 0.0f)) return fail(ODBOX_EINVAL, "%s: image_size must be positive", name);
+    const uint64_t total = (uint64_t)B * (uint64_t)max_items;
+    if (total > 0x7fffffffull) return fail(ODBOX_EINVAL, "%s: too many rows", name);
+    const dim3 grid((uint32_t)((total + 255) / 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, block, 0, st, src, labels, row_offsets, sizes, B, max_items, image_size, mode,
+                           (float4 *)out_boxes, out_labels);
+    };
+    if (from_xywh) { if (half_round) launch(gt_prepare_kernel<true, true>); else launch(gt_prepare_kernel<true, false>); }
+    else           { if (half_round) launch(gt_prepare_kernel<false, true>); else launch(gt_prepare_kernel<false, false>); }
+    return launch_status(name);
+}
+
+}  // namespace
+
+extern "C" {
+
+int odbox_gt_prepare_xywh(const float *boxes_xywh, const int32_t *labels, const int32_t *row_offsets,
+                          const float *orig_hw, int B, int max_items, float image_size, int half_round, int mode,
+                          float *out_boxes, int32_t *out_labels, void *stream)
+{
+    return gt_prepare("odbox_gt_prepare_xywh", true, boxes_xywh, labels, row_offsets, orig_hw, B, max_items, image_size,
+                      half_round, mode, out_boxes, out_labels, stream);
+}
+
+int odbox_gt_prepare_poly(const float *polys, const int32_t *labels, const int32_t *row_offsets, const float *canvas_size,
+                          int B, int max_items, float image_size, int half_round, int mode, float *out_boxes,
+                          int32_t *out_labels, void *stream)
+{
+    return gt_prepare("odbox_gt_prepare_poly", false, polys, labels, row_offsets, canvas_size, B, max_items, image_size,
+                      half_round, mode, out_boxes, out_labels, stream);
 }
 
 }  // extern "C"

@@ -393,3 +393,64 @@ def model_metric(anchors, image_hw, true_bboxes, true_labels, pred_bboxes, pred_
     gs = np.where((p64 >= eps) & (p64 <= hi), gs, 0.0)
     gs = np.where(not_ignore[:, :, None], gs, 0.0)
     return dist_loss, class_loss, normalizer, gb, gs
+
+
+# ----------------------------------------------------------------------------------------
+# ground-truth preparation feeding the matcher (detection.py)
+# ----------------------------------------------------------------------------------------
+
+def polygon2bbox(poly, want_yx=False, want_wh=False):
+    """detection.py:77-95.  poly [N,4,2] -> [N,4], in poly's dtype (fp32 or fp16)."""
+    poly = np.asarray(poly)
+    x, y = poly[..., 0], poly[..., 1]
+    xmin, ymin = x.min(axis=1, keepdims=True), y.min(axis=1, keepdims=True)
+    xmax, ymax = x.max(axis=1, keepdims=True), y.max(axis=1, keepdims=True)
+    if want_yx:
+        return np.concatenate([ymin, xmin, ymax, xmax], 1)
+    if want_wh:
+        return np.concatenate([xmin, ymin, (xmax - xmin).astype(poly.dtype), (ymax - ymin).astype(poly.dtype)], 1)
+    return np.concatenate([xmin, ymin, xmax, ymax], 1)
+
+
+def prepare_example_boxes(orig_bboxes, orig_labels, orig_hw, image_size, max_items, dtype=np.float32,
+                          want_yx=False, want_wh=False):
+    """The box arithmetic of detection.py:97-141 on the evaluation path (no augmentation):
+    orig_bboxes [n,4] = (x0, y0, w, h) in original pixels, orig_hw = (height, width) of the image.
+    Returns (new_bboxes [min(n,max_items),4] in `dtype`, new_labels)."""
+    bb = _f32(orig_bboxes).reshape(-1, 4)
+    x0, y0, w, h = (bb[:, k:k + 1] for k in range(4))                       # :98
+    H, W = F32(orig_hw[0]), F32(orig_hw[1])                                 # :100-101
+    mx = np.maximum(H, W)                                                   # :103
+    x0 = x0 + (mx - W) / F32(2)                                             # :110
+    y0 = y0 + (mx - H) / F32(2)                                             # :111
+    p0 = np.concatenate([x0, y0], 1)                                        # :118-121
+    p1 = np.concatenate([x0 + w, y0], 1)
+    p2 = np.concatenate([x0 + w, y0 + h], 1)
+    p3 = np.concatenate([x0, y0 + h], 1)
+    poly = np.stack([p0, p1, p2, p3], 1).astype(F32)                        # :123
+    cur = F32(int(mx))                                                      # :104-109,131
+    return prepare_polygons(poly, orig_labels, cur, image_size, max_items, dtype, want_yx, want_wh)
+
+
+def prepare_polygons(word_poly, labels, current_image_size, image_size, max_items, dtype=np.float32,
+                     want_yx=False, want_wh=False):
+    """detection.py:131-141: rescale the corner polygons [n,4,2] to the network input, cast to the
+    image dtype, polygon2bbox, cut at max_items_in_image."""
+    poly = _f32(word_poly).reshape(-1, 4, 2)
+    poly = ((poly / F32(current_image_size)).astype(F32) * F32(image_size)).astype(F32)   # :135
+    poly = poly.astype(dtype)                                                # :136
+    boxes = polygon2bbox(poly, want_yx, want_wh)                             # :138
+    return boxes[:max_items], np.asarray(labels, dtype=I32)[:max_items]     # :140-141
+
+
+def padded_batch_boxes(examples, max_items):
+    """detection.py:257-262 for the two GT tensors: examples = [(boxes [n_i,4], labels [n_i])],
+    padded with -1 to [B,max_items,4] fp32 / [B,max_items] int32."""
+    B = len(examples)
+    out_b = np.full((B, max_items, 4), -1, dtype=F32)
+    out_l = np.full((B, max_items), -1, dtype=I32)
+    for b, (bb, ll) in enumerate(examples):
+        n = len(ll)
+        out_b[b, :n] = np.asarray(bb, dtype=F32)
+        out_l[b, :n] = ll
+    return out_b, out_l

@@ -237,3 +237,20 @@ def test_model_metric_normaliser_and_gradient_consistency():
         num = (O.model_metric(anchors, (128, 128), gt, lab, pb, up, 3)[1] -
                O.model_metric(anchors, (128, 128), gt, lab, pb, dn, 3)[1]) * n / (2 * h)
         np.testing.assert_allclose(gs[0, i, k], num, rtol=2e-3)
+
+
+def test_gt_preparation_known_answers():
+    """detection.py:97-141: 300x400 image -> 400 canvas (y offset 50), rescale to 512."""
+    b, l = O.prepare_example_boxes([[10, 20, 30, 40], [0, 0, 400, 300]], [7, 3], (300, 400), 512, 64)
+    np.testing.assert_allclose(b, [[12.8, 89.6, 51.2, 140.8], [0, 64, 512, 448]], rtol=1e-6)
+    assert l.tolist() == [7, 3] and b.dtype == np.float32
+    b, l = O.prepare_example_boxes(np.tile([[1, 1, 2, 2]], (5, 1)), np.arange(5), (100, 100), 100, 3)
+    assert b.shape == (3, 4) and l.tolist() == [0, 1, 2]                # cut at max_items_in_image
+    pb, pl = O.padded_batch_boxes([(b, l), (np.zeros((0, 4)), np.zeros(0))], 4)
+    assert pb.shape == (2, 4, 4) and (pb[0, 3] == -1).all() and (pb[1] == -1).all() and pl[1].tolist() == [-1] * 4
+    poly = np.array([[[3, 9], [7, 1], [5, 5], [2, 4]]], np.float32)     # a rotated quadrilateral
+    assert O.polygon2bbox(poly).tolist() == [[2, 1, 7, 9]]
+    assert O.polygon2bbox(poly, want_yx=True).tolist() == [[1, 2, 9, 7]]
+    assert O.polygon2bbox(poly, want_wh=True).tolist() == [[2, 1, 5, 8]]
+    h, _ = O.prepare_example_boxes([[10, 20, 30, 40]], [1], (300, 400), 512, 4, np.float16)
+    assert h.dtype == np.float16 and h.tolist() == [[12.796875, 89.625, 51.1875, 140.75]]

@@ -43,14 +43,15 @@ def grid(cfg):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--cfg', type=int, nargs='*', default=[1, 2, 3, 4, 5])
+    ap.add_argument('--cfg', type=int, nargs='*', default=[1, 2, 3, 4, 5, 6],
+                    help='1-5: BASELINE.json configs; 6: evaluation side (COCO matching) on the gathered cfg-5 batch')
     ap.add_argument('--iters', type=int, default=20)
     args = ap.parse_args()
     lib = _lib.load()
     dev = _lib.require_gpu()
     st = _lib.stream_ptr()
     rows = []
-    for cfg in args.cfg:
+    for cfg in [x for x in args.cfg if x != 6]:
         c = workloads.CONFIGS[cfg]
         anchors = grid(cfg)
         N = anchors.shape[0]
@@ -105,6 +106,44 @@ def main():
             byts = B * (N * (32 + 4 * C) + 20 * G) * (1 if g1 is None else 2)
             rows.append(dict(cfg=name, B=B, N=N, G=G, C=C, us=t * 1e6, img_s=B / t, GBs=byts / t / 1e9,
                              frac_hbm=byts / t / 1e9 / HBM))
+    # COCO matching of the gathered detections of one cfg-5 eval batch (512 images)
+    if 6 in args.cfg:
+        import ctypes
+        import time
+        import numpy as np
+        from object_detection_amd import cocoeval as CE
+        B, R, G, C = 512, 100, 64, 90
+        d = workloads.eval_inputs(B=B, R=R, G=G, C=C)
+        dev_d = {k: torch.as_tensor(v).to(dev) for k, v in d.items()}
+        p = CE.Params()
+        thr = np.ascontiguousarray(p.iouThrs, dtype=np.float64)
+        rng = np.ascontiguousarray(p.areaRng, dtype=np.float64)
+        T, A = len(thr), len(rng)
+        dtm = torch.empty((B, A, T, R), dtype=torch.int32, device=dev)
+        dti = torch.empty((B, A, T, R), dtype=torch.uint8, device=dev)
+        gtm = torch.empty((B, A, T, G), dtype=torch.int32, device=dev)
+        gti = torch.empty((B, A, G), dtype=torch.uint8, device=dev)
+        rank = torch.empty((B, R), dtype=torch.int32, device=dev)
+        ws = torch.empty(lib.odbox_coco_match_workspace(B, R), dtype=torch.uint8, device=dev)
+
+        def step():
+            rc = lib.odbox_coco_match(dev_d['dt_boxes'].data_ptr(), dev_d['dt_scores'].data_ptr(),
+                                      dev_d['dt_labels'].data_ptr(), dev_d['gt_boxes'].data_ptr(),
+                                      dev_d['gt_labels'].data_ptr(), B, R, G, C, thr.ctypes.data_as(ctypes.c_void_p), T,
+                                      rng.ctypes.data_as(ctypes.c_void_p), A, 100, dtm.data_ptr(), dti.data_ptr(),
+                                      gtm.data_ptr(), gti.data_ptr(), rank.data_ptr(), ws.data_ptr(), ws.numel(), st)
+            assert rc == 0
+        t = event_time(step, args.iters)
+        byts = B * (R * 24 + G * 20 + A * T * (R * 5 + G * 4) + A * G + R * 4)
+        row = dict(cfg='6_coco_match', B=B, R=R, G=G, C=C, us=t * 1e6, img_s=B / t, GBs=byts / t / 1e9,
+                   frac_hbm=byts / t / 1e9 / HBM, pairs_per_s=B * A * T * R * 20 / t)
+        from oracle import coco_oracle as CO
+        n = 16
+        t0 = time.perf_counter()
+        CO.dense_eval(d['dt_boxes'][:n], d['dt_scores'][:n], d['dt_labels'][:n], d['gt_boxes'][:n], d['gt_labels'][:n],
+                      (512, 512), C)
+        row['cpu_oracle_img_s'] = n / (time.perf_counter() - t0)
+        rows.append(row)
     for r in rows:
         print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}))
 
