@@ -11,6 +11,8 @@ resident in HBM.  Images are independent, so ranks hold different images and exc
 (weak scaling).  The same JSON line carries
   roofline      the match_encode kernel against the 8 TB/s HBM peak (algorithmic bytes / HIP-event time),
   cpu_baseline  the oracle's C restatement timed on this host's cores on a bounded sample,
+  match_loss    SURVEY.md 8f row 1 on the same batch: matcher fused with the focal + Huber loss
+                (odbox_match_loss; the dense targets are never written), forward and forward+gradients,
   decode_nms    the inference-side path (configs[4]: 49 104 anchors, 90 classes, 64 images per GPU,
                 + one RCCL all-gather of the detections when N > 1), reported beside it.
 """
@@ -101,6 +103,8 @@ def main():
     ap.add_argument('--nms-steps', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-nms', action='store_true')
+    ap.add_argument('--no-loss', action='store_true')
+    ap.add_argument('--loss-steps', type=int, default=50)
     args = ap.parse_args()
 
     rank, world = oddist.init_from_env()
@@ -160,6 +164,35 @@ def main():
                      'bytes_per_launch': bytes_per_launch, 'us_per_launch': round(kernel_s * 1e6, 3),
                      'traffic': load_traffic('match_encode_kernel')},
     }
+
+    # ---------------- fused matcher + loss on the same batch ----------
+    if not args.no_loss:
+        gen = torch.Generator(device=dev).manual_seed(4242 + rank)
+        pb = torch.randn((B, N, 4), device=dev, generator=gen)
+        ps = torch.rand((B, N, C), device=dev, generator=gen)
+        out4 = torch.empty(4, dtype=torch.float32, device=dev)
+        gb, gs = torch.empty_like(pb), torch.empty_like(ps)
+        ws = torch.empty(lib.odbox_match_loss_workspace(B, N), dtype=torch.uint8, device=dev)
+        result['match_loss'] = {}
+        for name, g1, g2 in (('forward', None, None), ('forward_backward', gb, gs)):
+            def loss_step():
+                rc = lib.odbox_match_loss(anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C, float(S),
+                                          float(S), 0.4, 0.5, pb.data_ptr(), ps.data_ptr(), 1.5, 0.25, 1.0,
+                                          out4.data_ptr(), None if g1 is None else g1.data_ptr(),
+                                          None if g2 is None else g2.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+                if rc:
+                    _lib.check(rc, 'odbox_match_loss')
+            wl, el = timed(loss_step, args.loss_steps, 5, world)
+            byt = B * (N * (32 + 4 * C) + 20 * G) * (1 if g1 is None else 2)   # anchors + predictions (+ gradients)
+            ach = byt / (el / args.loss_steps) / 1e9
+            result['match_loss'][name] = {
+                'value': round(world * B * args.loss_steps / wl, 1), 'unit': 'images/s',
+                'us_per_step': round(el / args.loss_steps * 1e6, 2), 'steps': args.loss_steps,
+                'roofline': {'bound': 'hbm', 'kernel': 'match_loss_kernel + loss_reduce_kernel', 'achieved': round(ach, 1),
+                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
+                             'bytes_per_launch': byt,
+                             'traffic': load_traffic('match_loss_kernel_fwd' if g1 is None else 'match_loss_kernel_fwd_bwd')}}
+        del pb, ps, gb, gs
 
     # ---------------- decode + NMS, configs[4] per-GPU share -------------------------------
     if not args.no_nms:

@@ -17,8 +17,12 @@ for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
     for f in glob.glob(os.path.join(root, counter, '*', '*counter_collection.csv')):
         for r in csv.DictReader(open(f)):
             name = r['Kernel_Name']
-            for k in ('match_encode_kernel', 'score_scan_kernel', 'nms_kernel', 'finalize_kernel', 'cand_partition_kernel'):
-                if k in name:
+            for k, pat in (('match_loss_kernel_fwd', 'match_loss_kernel<false'),
+                           ('match_loss_kernel_fwd_bwd', 'match_loss_kernel<true'),
+                           ('match_encode_kernel', 'match_encode_kernel'), ('score_scan_kernel', 'score_scan_kernel'),
+                           ('nms_kernel', 'nms_kernel'), ('finalize_kernel', 'finalize_kernel'),
+                           ('cand_partition_kernel', 'cand_partition_kernel')):
+                if pat in name:
                     vals[k][r['Counter_Name']].append(float(r['Counter_Value']))
 out = {}
 for k, v in vals.items():
