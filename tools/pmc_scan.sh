@@ -5,5 +5,5 @@ mkdir -p $OUT
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d $OUT/set$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --nms-steps 3 --no-cpu-baseline > $OUT/set$i.log 2>&1 || exit 1
+  timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d $OUT/set$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --nms-steps 3 --loss-steps 2 --no-cpu-baseline > $OUT/set$i.log 2>&1 || exit 1
 done
