@@ -165,3 +165,43 @@ def test_idempotent_and_workspace_reuse():
     for x, y in zip(first, again):
         assert torch.equal(x, y)
     check(small, c_oracle.decode_nms(anchors[:100], regress[:, :100], scores[:, :100], (160, 160)))
+
+
+@pytest.mark.parametrize('max_ret', [3, 100, 600])
+def test_segment_sizes_around_the_cooperative_block_path(max_ret):
+    """One class per image with exactly m candidates: m <= 128 runs as one wave, 129..512 as a
+    cooperating block (one wave per 64 candidates), > 512 on the presorted path; same keep-list."""
+    sizes = [64, 65, 128, 129, 130, 191, 192, 193, 256, 257, 320, 448, 511, 512, 513, 700]
+    rng = np.random.default_rng(77 + max_ret)
+    N, C, B = 1800, 2, len(sizes)
+    anchors = O.tile_anchors(O.base_anchors(32, (1, 2, .5)), 15, 15, 8)[:N]
+    regress = np.clip(rng.normal(0, 0.4, (B, N, 4)), -2, 2).astype(F)
+    scores = rng.uniform(0, 0.2, (B, N, C)).astype(F)
+    for b, m in enumerate(sizes):
+        idx = rng.choice(N, m, replace=False)
+        scores[b, idx, 1] = (np.floor((0.3 + 0.7 * rng.uniform(size=m)) * 32) / 32 + 1 / 64).astype(F)   # many exact ties
+        scores[b, rng.choice(N, 40, replace=False), 0] = 0.25          # below the threshold: class 0 stays empty
+    got = BB.decode_and_nms(anchors, regress, scores, (128, 128), max_ret=max_ret, return_keep=True)
+    want = c_oracle.decode_nms(anchors, regress, scores, (128, 128), max_ret=max_ret, threads=4)
+    check(got, want)
+    assert want[4].min() > 0
+
+
+def test_cooperative_block_with_mixed_segments_in_one_image():
+    """Big and small classes side by side (the big ones leave through the block path, the others
+    through the wave path, both append to the same per-image list)."""
+    rng = np.random.default_rng(5)
+    N, C, B = 3000, 6, 3
+    anchors = O.tile_anchors(O.base_anchors(24, (1, 2, .5)), 19, 19, 8)[:N]
+    regress = np.clip(rng.normal(0, 0.5, (B, N, 4)), -2, 2).astype(F)
+    scores = rng.uniform(0, 0.2, (B, N, C)).astype(F)
+    for b in range(B):
+        perm = rng.permutation(N)
+        at = 0
+        for c, m in enumerate((300, 20, 150, 0, 500, 90)):
+            idx = perm[at:at + m]
+            at += m
+            scores[b, idx, c] = (np.floor((0.3 + 0.7 * rng.uniform(size=m)) * 256) / 256).astype(F)
+    got = BB.decode_and_nms(anchors, regress, scores, (160, 160), max_ret=100, return_keep=True)
+    want = c_oracle.decode_nms(anchors, regress, scores, (160, 160), max_ret=100, threads=4)
+    check(got, want)
