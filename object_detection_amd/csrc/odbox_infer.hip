@@ -907,6 +907,8 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
     uint32_t total_segments, int waves_per_block, uint32_t per_wave_bytes, uint32_t dbg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    if ((dbg & 4u) && blockIdx.x < coop_blocks) return;       // timing experiments: one path only
+    if ((dbg & 8u) && blockIdx.x >= coop_blocks) return;
     if (blockIdx.x < coop_blocks)
         nms_coop_block(s_raw, blockIdx.x, coop_blocks, anchors, rb, N, C, do_clip, hi_x, hi_y, thr, max_ret, cand_keys,
                        cand_stride, seg_start, coop_count, coop_list, fin_count, fin_keys, fin_stride);

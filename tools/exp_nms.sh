@@ -1,1 +1,13 @@
-for bpc in 1 2 3 4; do echo "nms blocks/CU=$bpc"; ODBOX_NMS_BLOCKS_PER_CU=$bpc timeout -k 10 100 python bench.py --steps 5 --warmup 2 --nms-steps 30 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['decode_nms']['ms_per_step'], d['decode_nms']['value'])"; done
+# NMS kernel time with one of its two paths switched off (ODBOX_NMS_DBG 4: no cooperative blocks, 8: no wave blocks)
+cd /tmp && export TMPDIR=/tmp
+for d in 0 4 8; do
+OUT=$GRAFT_REPO_ROOT/gpurun_out/nmsdbg$d
+rm -rf $OUT; mkdir -p $OUT
+ODBOX_NMS_DBG=$d timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/bench_configs.py --cfg 5 > $OUT/log.txt 2>&1 || exit 1
+echo "dbg=$d $(grep -h 'nms_kernel' $OUT/*/*kernel_stats.csv | awk -F'",' '{print $2,$3,$4}' | tr -d '"' | awk '{print $NF}' | head -1)"
+python3 -c "
+import csv,glob
+for r in csv.DictReader(open(glob.glob('$OUT/*/*kernel_stats.csv')[0])):
+    if 'nms_kernel' in r['Name']: print('   nms_kernel avg us', float(r['AverageNs'])/1000)
+"
+done
