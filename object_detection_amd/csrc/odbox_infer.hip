@@ -137,14 +137,14 @@ __global__ __launch_bounds__(WAVE) void score_scan_kernel(
     uint32_t total_tiles, int *__restrict__ tile_ticket, int *__restrict__ cand_count,
     uint64_t *__restrict__ cand_keys, uint32_t cand_stride, uint32_t nq_arg, uint32_t dbg)
 {
-    extern __shared__ __attribute__((aligned(16))) float s_buf[];
-    __shared__ uint64_t s_pend[SCAN_MAX_ROWS];          // candidate keys of the tile just reduced
+    extern __shared__ __attribute__((aligned(16))) float s_buf[];     // 2 tile buffers, then the pending keys
     constexpr uint32_t LPR = 1u << LL;                  // lanes per row
     constexpr uint32_t G = WAVE >> LL;                  // rows per wave-step
     const uint32_t lane = threadIdx.x;
     const uint32_t sub = lane & (LPR - 1);
     const uint32_t grp = lane >> LL;
     const uint32_t R = (uint32_t)g.steps * G;
+    uint64_t *s_pend = reinterpret_cast<uint64_t *>(s_buf + 2u * g.buf_floats);   // [R] keys of the tile just reduced
     const uint32_t lds_base = lds_address(s_buf);
     const uint32_t stride_k = LPR * V;                  // floats between a lane's consecutive reads
 
@@ -631,7 +631,7 @@ __device__ __forceinline__ void nms_wave_segment(
     int C, int do_clip, float hi_x, float hi_y, NmsThr thr, int max_ret, const uint64_t *__restrict__ cand_keys,
     uint32_t cand_stride, const int *__restrict__ seg_start, const int *__restrict__ big_flag,
     int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys, uint32_t fin_stride,
-    uint32_t total_segments, int waves_per_block, uint32_t per_wave_bytes, bool coop_on, uint32_t dbg)
+    uint32_t total_segments, int waves_per_block, uint32_t per_wave_bytes, uint32_t sort_cap, bool coop_on, uint32_t dbg)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -644,12 +644,12 @@ __device__ __forceinline__ void nms_wave_segment(
     if (end <= start) return;
     const uint32_t m = (uint32_t)(end - start);
 
-    // per-wave LDS: [sorted segment keys: NMS_SEG_LDS][kept keys: max_ret][kept boxes and areas
+    // per-wave LDS: [sorted segment keys: sort_cap][kept keys: max_ret][kept boxes and areas
     // beyond the register-resident NMS_REG_KEPT: extra * 20 bytes]
     unsigned char *mine = s_raw + (size_t)wave * per_wave_bytes;
     const int extra = max_ret > NMS_REG_KEPT ? max_ret - NMS_REG_KEPT : 0;
     uint64_t *s_sort = reinterpret_cast<uint64_t *>(mine);
-    uint64_t *s_key = s_sort + NMS_SEG_LDS;
+    uint64_t *s_key = s_sort + sort_cap;
     float4 *s_box = reinterpret_cast<float4 *>(s_key + ((max_ret + 1) & ~1)) - NMS_REG_KEPT;   // indexed by kept
     float *s_area = reinterpret_cast<float *>(s_box + NMS_REG_KEPT + extra) - NMS_REG_KEPT;
 
@@ -904,7 +904,7 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
     uint32_t cand_stride, const int *__restrict__ seg_start, const int *__restrict__ big_flag,
     const int *__restrict__ coop_count, const int *__restrict__ coop_list, uint32_t coop_blocks,
     int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys, uint32_t fin_stride,
-    uint32_t total_segments, int waves_per_block, uint32_t per_wave_bytes, uint32_t dbg)
+    uint32_t total_segments, int waves_per_block, uint32_t per_wave_bytes, uint32_t sort_cap, uint32_t dbg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     if ((dbg & 4u) && blockIdx.x < coop_blocks) return;       // timing experiments: one path only
@@ -915,7 +915,7 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
     else
         nms_wave_segment(s_raw, blockIdx.x - coop_blocks, anchors, rb, N, C, do_clip, hi_x, hi_y, thr, max_ret,
                          cand_keys, cand_stride, seg_start, big_flag, fin_count, fin_keys, fin_stride, total_segments,
-                         waves_per_block, per_wave_bytes, coop_blocks != 0, dbg);
+                         waves_per_block, per_wave_bytes, sort_cap, coop_blocks != 0, dbg);
 }
 
 // kernel 4: per image, order the kept detections like tf.math.top_k over the class-ordered
@@ -1130,10 +1130,10 @@ int launch_scan_inst(const float *scores, int B, int N, int C, const ScanGeom &g
     const uint64_t tiles = ((uint64_t)N + R - 1) / R;
     const uint64_t total = tiles * (uint64_t)B;
     if (total > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_decode_nms: too many score tiles");
-    const size_t lds = (size_t)2 * g.buf_floats * sizeof(float);
-    if (lds + SCAN_MAX_ROWS * 8 > 160 * 1024)
+    const size_t lds = (size_t)2 * g.buf_floats * sizeof(float) + (size_t)R * 8;
+    if (lds > 160 * 1024)
         return fail(ODBOX_EINVAL, "odbox_decode_nms: C=%d needs %zu bytes of LDS per wave", C, lds);
-    int per_cu = (int)((160 * 1024) / align_up(lds + SCAN_MAX_ROWS * 8, 1024));
+    int per_cu = (int)((160 * 1024) / align_up(lds, 1024));
     per_cu = per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu);
     if (const char *e = getenv("ODBOX_SCAN_WAVES_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;   // tuning aid
     uint32_t nq = SCAN_QUEUES, dbg = 0;
@@ -1246,8 +1246,15 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
 
     // kernel 3: per-(image, class) greedy NMS
     const size_t nms_extra = max_ret > NMS_REG_KEPT ? (size_t)(max_ret - NMS_REG_KEPT) : 0;
-    const size_t per_wave = align_up((size_t)NMS_SEG_LDS * 8 + (size_t)((max_ret + 1) & ~1) * 8 + nms_extra * 20, 16);
+    // with the cooperative blocks on, a wave only ever sorts <= NMS_COOP_MIN keys itself
+    const size_t kept_bytes = (size_t)((max_ret + 1) & ~1) * 8 + nms_extra * 20;
+    size_t per_wave = align_up((size_t)NMS_COOP_MIN * 8 + kept_bytes, 16);
+    uint32_t sort_cap = NMS_COOP_MIN;
     const int waves = per_wave * NMS_WAVES <= 64 * 1024 ? NMS_WAVES : 1;
+    if (waves != NMS_WAVES) {                                  // no cooperative blocks: up to NMS_SEG_LDS keys per wave
+        sort_cap = NMS_SEG_LDS;
+        per_wave = align_up((size_t)NMS_SEG_LDS * 8 + kept_bytes, 16);
+    }
     const uint64_t segs = (uint64_t)B * C;
     const NmsThr nms_thr = {iou_thr, iou_thr * (1.0f - 0x1p-20f), iou_thr * (1.0f + 0x1p-20f)};
     // cooperative blocks need the full block; their list is only built by the partition kernel
@@ -1259,7 +1266,7 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
     hipLaunchKernelGGL(nms_kernel, dim3((uint32_t)nms_grid), dim3(waves * WAVE), nms_lds, st, (const float4 *)anchors,
                        (const float4 *)regress_or_boxes, N, C, do_clip, hi_x, hi_y, nms_thr, max_ret, nms_keys,
                        L.cand_stride, seg_start, big_flag, (const int *)coop_count, (const int *)coop_list, coop_blocks,
-                       fin_count, fin_keys, L.fin_stride, (uint32_t)segs, waves, (uint32_t)per_wave,
+                       fin_count, fin_keys, L.fin_stride, (uint32_t)segs, waves, (uint32_t)per_wave, sort_cap,
                        (uint32_t)(getenv("ODBOX_NMS_DBG") ? atoi(getenv("ODBOX_NMS_DBG")) : 0));
     if (int r3 = launch_status("nms")) return r3;
 
