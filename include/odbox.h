@@ -4,8 +4,8 @@
  * The reference (bioothod/object_detection) has no FFI of its own: the path sits behind
  * plain Python module functions on tf.Tensor.  Each entry point below names
  * the reference function (file:line under the reference tree) whose arithmetic it replaces;
- * object_detection_amd/{anchors,bndbox}.py bind them with ctypes under the reference's own
- * Python signatures.
+ * object_detection_amd/{anchors,bndbox,metric,detection,cocoeval}.py bind them with ctypes
+ * under the reference's own Python signatures.
  *
  * Conventions
  *   - every pointer is a DEVICE pointer (hipMalloc / torch-ROCm storage) unless noted;

@@ -86,3 +86,57 @@ def test_no_cpu_fallback():
         g((4, 4, 3))
     with pytest.raises(_lib.OdboxError):
         bndbox.nms(np.zeros((1, 4, 4), np.float32), np.zeros((1, 4, 2), np.float32))
+
+
+def test_caller_side_signatures_are_kept():
+    """metric.py, detection.py and cocoeval.py: the callers either side of the path."""
+    from object_detection_amd import cocoeval, detection, metric
+
+    def params(f):
+        return list(inspect.signature(f).parameters)
+    assert params(metric.focal_loss)[:6] == ['y_true', 'y_pred', 'gamma', 'alpha', 'from_logits', 'reduction']
+    sig = inspect.signature(metric.focal_loss)
+    assert (sig.parameters['gamma'].default, sig.parameters['alpha'].default, sig.parameters['reduction'].default) == (1.5, 0.25, 'sum')
+    assert params(metric.ModelMetric.__init__)[:3] == ['self', 'all_anchors', 'num_classes']
+    assert params(metric.ModelMetric.__call__) == ['self', 'images', 'true_bboxes', 'true_labels', 'true_image_labels',
+                                                   'pred_bboxes', 'pred_scores', 'pred_image_scores', 'training']
+    assert params(detection.polygon2bbox) == ['poly', 'want_yx', 'want_wh']
+    assert detection.MAX_ITEMS_IN_IMAGE == 64 and detection.generate_anchors is anchors.generate_anchors
+    p = cocoeval.Params()                                              # cocoeval.py:506-515
+    np.testing.assert_array_equal(p.iouThrs, np.linspace(.5, .95, 10))
+    np.testing.assert_array_equal(p.recThrs, np.linspace(0, 1, 101))
+    assert p.maxDets == [1, 10, 100] and p.areaRngLbl == ['all', 'small', 'medium', 'large']
+    assert p.areaRng == [[0, 1e10], [0, 1024], [1024, 9216], [9216, 1e10]]
+    for name in ('accumulate', 'summarize', 'add_batch'):
+        assert callable(getattr(cocoeval.COCOeval, name))
+    ev = cocoeval.COCOeval(3)
+    ev.accumulate()                                                    # nothing fed: every entry stays -1
+    assert ev.eval['precision'].shape == (10, 101, 3, 4, 3) and (ev.eval['precision'] == -1).all()
+    assert (ev.summarize() == -1).all()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU behaviour')
+def test_no_cpu_fallback_in_the_caller_side_modules():
+    from object_detection_amd import cocoeval, detection, metric
+    z = np.zeros
+    with pytest.raises(_lib.OdboxError):
+        metric.focal_loss(z((2, 3), np.float32), z((2, 3), np.float32))
+    with pytest.raises(_lib.OdboxError):
+        metric.detection_loss(z((4, 4), np.float32), (8, 8), z((1, 1, 4), np.float32), z((1, 1), np.int32),
+                              z((1, 4, 4), np.float32), z((1, 4, 2), np.float32), 2)
+    with pytest.raises(_lib.OdboxError):
+        detection.prepare_batch([z((1, 4))], [z(1)], [(8, 8)], 16)
+    with pytest.raises(_lib.OdboxError):
+        cocoeval.evaluate_img(z((1, 2, 4)), z((1, 2)), z((1, 2)), z((1, 1, 4)), z((1, 1)), 2)
+    with pytest.raises(_lib.OdboxError):
+        cocoeval.compute_iou(z((1, 2, 4)), z((1, 1, 4)))
+
+
+def test_oracle_is_not_imported_by_the_product():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, 'object_detection_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert 'import oracle' not in text and 'from oracle' not in text and 'oracle/' not in text.replace('oracle/_', ''), f
