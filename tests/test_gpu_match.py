@@ -126,6 +126,20 @@ def test_cfg4_dense_crowd_slice():
     check_targets(anchors, (512, 512), gt, lab, 1)
 
 
+def test_cfg4_full_batch():
+    """cfg 4 at its full per-GPU size (B=128, 500 GT rows, 49 104 anchors): the C oracle needs ~4 s."""
+    anchors = O.generate_anchors(512)
+    gt, lab = workloads.match_inputs(4)
+    assert gt.shape == (128, 500, 4)
+    got = A.match_encode(anchors, (512, 512), gt, lab, 1, dense=True, compact=True)
+    ref = c_oracle.match_encode(anchors, (512, 512), gt, lab, 1, threads=8, dense=True)
+    np.testing.assert_array_equal(cpu(got['match_idx']), ref['match_idx'])
+    np.testing.assert_array_equal(cpu(got['state']), ref['state'])
+    np.testing.assert_array_equal(cpu(got['labels']), ref['labels'])
+    np.testing.assert_allclose(cpu(got['regression']), ref['regression'], rtol=1e-5, atol=1e-6)
+    assert (ref['state'] == 1).sum() > 1000 and (ref['state'] == -1).sum() > 1000
+
+
 def test_cfg3_large_properties():
     """cfg 3 at full per-GPU size (B=32, N=196416): compact outputs vs the oracle, dense outputs
     through size-independent properties (row sums / state column / one-hot position)."""

@@ -139,6 +139,36 @@ def test_cfg5_slice_full_anchor_set():
     assert want[4].min() > 10
 
 
+def test_cfg5_full_per_gpu_batch():
+    """cfg 5 at its full per-GPU size (64 images x 49 104 anchors x 90 classes, 1.13 GB of scores):
+    keep-lists against the C oracle, plus the size-independent properties of the output."""
+    anchors = O.generate_anchors(512)
+    N = anchors.shape[0]
+    regress, scores = workloads.nms_inputs(N, C=90, batch=64, distinct=16, p3p4_anchors=9 * (64 * 64 + 32 * 32))
+    got = BB.decode_and_nms(anchors, regress, scores, (512, 512), return_keep=True)
+    want = c_oracle.decode_nms(anchors, regress, scores, (512, 512), threads=8)
+    check(got, want)
+    boxes, sc, lab, keep, cnt = got
+    assert int(cnt.min()) == 100                                          # every image fills max_ret
+    assert bool((sc[:, :-1] >= sc[:, 1:]).all())                          # tf.math.top_k order
+    dev_scores = torch.as_tensor(scores).to(sc.device)
+    rows = torch.gather(dev_scores, 1, keep.long().unsqueeze(-1).expand(-1, -1, 90))
+    assert torch.equal(rows.max(-1).values, sc) and torch.equal(rows.argmax(-1).int(), lab)
+    # no two kept boxes of one class overlap by more than the threshold (plain torch IoU)
+    x0, y0, x1, y1 = boxes.unbind(-1)
+    area = (x1 - x0) * (y1 - y0)
+    iw = (torch.minimum(x1[:, :, None], x1[:, None, :]) - torch.maximum(x0[:, :, None], x0[:, None, :])).clamp(min=0)
+    ih = (torch.minimum(y1[:, :, None], y1[:, None, :]) - torch.maximum(y0[:, :, None], y0[:, None, :])).clamp(min=0)
+    inter = iw * ih
+    iou = inter / (area[:, :, None] + area[:, None, :] - inter)
+    same = (lab[:, :, None] == lab[:, None, :]) & ~torch.eye(100, dtype=torch.bool, device=lab.device)
+    assert float(iou[same & (area[:, :, None] > 0) & (area[:, None, :] > 0)].max()) <= 0.45 + 1e-6
+    # idempotence: NMS of the kept boxes with their own one-hot scores keeps all of them, in order
+    onehot = torch.zeros((64, 100, 90), device=sc.device).scatter_(2, lab.long().unsqueeze(-1), sc.unsqueeze(-1))
+    b2, s2, l2 = BB.nms(boxes, onehot)
+    assert torch.equal(s2, sc) and torch.equal(l2, lab) and torch.equal(b2, boxes)
+
+
 def test_pre_nms_topk_extension():
     rng = np.random.default_rng(3)
     anchors, regress, scores = _case(rng, 2, 2000, 9, 1500, quant=1 << 20)
