@@ -100,3 +100,33 @@ def test_cfg2_full_size_loss():
     rd, rc, rn = O.model_metric(anchors, (416, 416), gt, lab, pb, ps, 80)
     assert float(n) == rn
     np.testing.assert_allclose([float(d), float(c)], [rd, rc], rtol=RTOL)
+
+
+def test_cfg2_full_batch_losses_and_gradients():
+    """The bench workload at full size (64 images, 10 647 anchors, 80 classes): losses against the
+    oracle, gradients through a linearity check that needs no full-size reference gradient:
+    (loss(p + h d) - loss(p - h d)) / 2h ~= <grad, d>."""
+    anchors = O.yolo_shaped_anchors(416)
+    gt, lab = workloads.match_inputs(2)
+    rng = np.random.default_rng(0)
+    N = anchors.shape[0]
+    pb = rng.normal(0, 1, (64, N, 4)).astype(F)
+    ps = rng.uniform(0.02, 0.98, (64, N, 80)).astype(F)
+    d, c, n, gb, gs = M.detection_loss(anchors, (416, 416), gt, lab, pb, ps, 80, return_grads=True)
+    rd, rc, rn = O.model_metric(anchors, (416, 416), gt, lab, pb, ps, 80)
+    assert float(n) == rn
+    np.testing.assert_allclose([float(d), float(c)], [rd, rc], rtol=RTOL)
+    d0, c0, _ = M.detection_loss(anchors, (416, 416), gt, lab, pb, ps, 80)
+    assert float(d0) == float(d) and float(c0) == float(c)                 # forward-only launch: same sums
+    # directions correlated with the gradient (sign(g) * |N(0,1)|): no cancellation in <grad, d>, so a
+    # relative tolerance means something; central differences of fp32 sums resolve about a percent
+    h = 2e-4
+    db = (np.abs(rng.normal(0, 1, pb.shape)) * np.sign(gb.cpu().numpy())).astype(F)
+    ds = (np.abs(rng.normal(0, 1, ps.shape)) * np.sign(gs.cpu().numpy())).astype(F)
+    d1, c1, _ = M.detection_loss(anchors, (416, 416), gt, lab, pb + h * db, ps + h * ds, 80)
+    d2, c2, _ = M.detection_loss(anchors, (416, 416), gt, lab, pb - h * db, ps - h * ds, 80)
+    lin_d = float((gb * torch.as_tensor(db).to(gb.device)).double().sum())
+    lin_c = float((gs * torch.as_tensor(ds).to(gs.device)).double().sum())
+    assert lin_d > 0 and lin_c > 0
+    np.testing.assert_allclose((float(d1) - float(d2)) / (2 * h), lin_d, rtol=0.02)
+    np.testing.assert_allclose((float(c1) - float(c2)) / (2 * h), lin_c, rtol=0.02)
