@@ -445,7 +445,10 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
     for (int c = tid; c < C; c += PART_THREADS) s_hist[c] = 0;
     if (tid == 0) s_scan[PART_THREADS] = 0;
     __syncthreads();
-    for (uint32_t i = tid; i < M; i += PART_THREADS) atomicAdd(&s_hist[key_class(in[i])], 1);
+    // (class / anchor ids are clamped wherever they index memory: a corrupted workspace must give
+    // wrong answers, never a fault)
+    const uint32_t cmax = (uint32_t)C - 1u;
+    for (uint32_t i = tid; i < M; i += PART_THREADS) atomicAdd(&s_hist[min(key_class(in[i]), cmax)], 1);
     __syncthreads();
     // exclusive scan over classes: each thread owns a contiguous chunk
     const int chunk = (C + PART_THREADS - 1) / PART_THREADS;
@@ -476,11 +479,15 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
     if (!big)
         for (int c = c0; c < c1; ++c) {
             const int cnt = (c + 1 < C ? seg[c + 1] : (int)M) - seg[c];
-            if (cnt > NMS_COOP_MIN) coop_list[atomicAdd(coop_count, 1)] = (int)(b * (uint32_t)C + (uint32_t)c);
+            if (cnt > NMS_COOP_MIN) {
+                const uint32_t at = (uint32_t)atomicAdd(coop_count, 1);
+                if (at < gridDim.x * (uint32_t)C) coop_list[at] = (int)(b * (uint32_t)C + (uint32_t)c);
+            }
         }
     for (uint32_t i = tid; i < M; i += PART_THREADS) {
         const uint64_t k = in[i];
-        out[atomicAdd(&s_hist[key_class(k)], 1)] = k;
+        const uint32_t at = (uint32_t)atomicAdd(&s_hist[min(key_class(k), cmax)], 1);
+        if (at < M) out[at] = k;
     }
     if (!big) return;                                    // block-uniform
     if (tid == 0) big_flag[b] = 1;
@@ -550,6 +557,7 @@ __device__ __forceinline__ float4 candidate_box(const float4 *__restrict__ ancho
                                                 const float4 *__restrict__ rb, size_t b, int N,
                                                 uint32_t idx, int do_clip, float hi_x, float hi_y)
 {
+    idx = min(idx, (uint32_t)N - 1u);
     float4 v = rb[b * (size_t)N + idx];
     if (anchors) v = regress_one(anchors[idx], v);
     if (do_clip) v = clip_one(v, hi_x, hi_y);
@@ -790,8 +798,8 @@ __device__ __forceinline__ void nms_coop_block(
     unsigned char *s_raw, uint32_t block, uint32_t nblocks, const float4 *__restrict__ anchors,
     const float4 *__restrict__ rb, int N, int C, int do_clip, float hi_x, float hi_y, NmsThr thr, int max_ret,
     const uint64_t *__restrict__ cand_keys, uint32_t cand_stride, const int *__restrict__ seg_start,
-    const int *__restrict__ coop_count, const int *__restrict__ coop_list, int *__restrict__ fin_count,
-    uint64_t *__restrict__ fin_keys, uint32_t fin_stride)
+    const int *__restrict__ coop_count, const int *__restrict__ coop_list, uint32_t total_segments,
+    int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys, uint32_t fin_stride)
 {
     static_assert(NMS_WAVES * WAVE == (int)NMS_SEG_LDS, "one wave per 64-candidate chunk");
     uint64_t *s_key = reinterpret_cast<uint64_t *>(s_raw);                         // sorted keys
@@ -803,12 +811,12 @@ __device__ __forceinline__ void nms_coop_block(
     int *s_base = s_nkept + NMS_WAVES;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const int items = *coop_count;
+    const int items = min(*coop_count, (int)total_segments);
     for (int item = (int)block; item < items; item += (int)nblocks) {
-        const uint32_t seg_id = (uint32_t)coop_list[item];
+        const uint32_t seg_id = min((uint32_t)coop_list[item], total_segments - 1u);
         const uint32_t b = seg_id / (uint32_t)C, c = seg_id - b * (uint32_t)C;
         const int start = seg_start[(size_t)b * (C + 1) + c];
-        const uint32_t m = (uint32_t)(seg_start[(size_t)b * (C + 1) + c + 1] - start);   // NMS_COOP_MIN < m <= NMS_SEG_LDS
+        const uint32_t m = min((uint32_t)max(seg_start[(size_t)b * (C + 1) + c + 1] - start, 0), NMS_SEG_LDS);   // NMS_COOP_MIN < m <= NMS_SEG_LDS
         const uint32_t nw = (m + WAVE - 1) / WAVE;
 
         // (1) rank sort: keys are distinct (the anchor id is part of the key), so the number of smaller
@@ -896,6 +904,15 @@ __device__ __forceinline__ void nms_coop_block(
     }
 }
 
+// kernel 0: zero the header of the workspace (counters, flags, tile tickets).  A kernel of our own
+// rather than hipMemsetAsync: under HIP graph capture the memset node was observed to race with
+// the scan that follows it (wrong counters on replay); a kernel node keeps stream order.
+__global__ __launch_bounds__(256) void zero_header_kernel(uint4 *__restrict__ p, uint32_t n16)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // kernel 3: the first coop_blocks blocks take the big segments cooperatively (they start first, so
 // the longest chains overlap everything else), the others run one wave per (image, class) segment.
 __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
@@ -911,7 +928,7 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
     if ((dbg & 8u) && blockIdx.x >= coop_blocks) return;
     if (blockIdx.x < coop_blocks)
         nms_coop_block(s_raw, blockIdx.x, coop_blocks, anchors, rb, N, C, do_clip, hi_x, hi_y, thr, max_ret, cand_keys,
-                       cand_stride, seg_start, coop_count, coop_list, fin_count, fin_keys, fin_stride);
+                       cand_stride, seg_start, coop_count, coop_list, total_segments, fin_count, fin_keys, fin_stride);
     else
         nms_wave_segment(s_raw, blockIdx.x - coop_blocks, anchors, rb, N, C, do_clip, hi_x, hi_y, thr, max_ret,
                          cand_keys, cand_stride, seg_start, big_flag, fin_count, fin_keys, fin_stride, total_segments,
@@ -1216,7 +1233,11 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
     uint64_t *fin_keys = (uint64_t *)(ws + L.off_fin);
     const float hi_x = img_w - 1.0f, hi_y = img_h - 1.0f;
 
-    HIP_TRY(hipMemsetAsync(ws, 0, L.off_seg, st));      // counters, flags, tile tickets
+    {   // counters, flags, tile tickets (L.off_seg is a multiple of 256 bytes)
+        const uint32_t n16 = (uint32_t)(L.off_seg / 16);
+        hipLaunchKernelGGL(zero_header_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, (uint4 *)ws, n16);
+        if (int r0 = launch_status("zero_header")) return r0;
+    }
 
     // kernel 1: score scan -> unordered candidate keys per image
     const ScanGeom g = scan_geometry(C, N);
