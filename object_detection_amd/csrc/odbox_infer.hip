@@ -448,23 +448,40 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
     // (class / anchor ids are clamped wherever they index memory: a corrupted workspace must give
     // wrong answers, never a fault)
     const uint32_t cmax = (uint32_t)C - 1u;
-    for (uint32_t i = tid; i < M; i += PART_THREADS) atomicAdd(&s_hist[min(key_class(in[i]), cmax)], 1);
+    // the usual list (<= PART_REG * 512 keys) stays in registers between the two passes: every load
+    // is issued before the first use, and the scatter pass reads nothing from memory
+    constexpr int PART_REG = 16;
+    const bool in_regs = M <= (uint32_t)(PART_REG * PART_THREADS);
+    uint64_t kreg[PART_REG];
+    if (in_regs) {
+#pragma unroll
+        for (int r = 0; r < PART_REG; ++r) {
+            const uint32_t i = tid + (uint32_t)r * PART_THREADS;
+            kreg[r] = i < M ? in[i] : ~0ull;
+        }
+#pragma unroll
+        for (int r = 0; r < PART_REG; ++r)
+            if (tid + (uint32_t)r * PART_THREADS < M) atomicAdd(&s_hist[min(key_class(kreg[r]), cmax)], 1);
+    } else {
+        for (uint32_t i = tid; i < M; i += PART_THREADS) atomicAdd(&s_hist[min(key_class(in[i]), cmax)], 1);
+    }
     __syncthreads();
-    // exclusive scan over classes: each thread owns a contiguous chunk
+    // exclusive scan over classes: each thread owns a contiguous chunk; wave scans + 8 wave totals
     const int chunk = (C + PART_THREADS - 1) / PART_THREADS;
     const int c0 = min((int)tid * chunk, C), c1 = min(c0 + chunk, C);
     int local = 0, biggest = 0;
     for (int c = c0; c < c1; ++c) { local += s_hist[c]; biggest = max(biggest, s_hist[c]); }
-    s_scan[tid] = local;
     if (biggest > (int)NMS_SEG_LDS) s_scan[PART_THREADS] = 1;
-    __syncthreads();
-    for (int off = 1; off < PART_THREADS; off <<= 1) {
-        const int v = tid >= (uint32_t)off ? s_scan[tid - off] : 0;
-        __syncthreads();
-        s_scan[tid] += v;
-        __syncthreads();
+    int incl = local;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if ((int)(tid & 63u) >= off) incl += v;
     }
-    int run = s_scan[tid] - local;
+    if ((tid & 63u) == 63u) s_scan[tid >> 6] = incl;
+    __syncthreads();
+    int run = incl - local;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) run += s_scan[w];
     int *seg = seg_start + (size_t)b * (C + 1);
     for (int c = c0; c < c1; ++c) {
         const int cnt = s_hist[c];
@@ -475,7 +492,7 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
     if (tid == 0) seg[C] = (int)M;
     const bool big = s_scan[PART_THREADS] != 0;
     __syncthreads();
-    // segments of NMS_COOP_MIN < m <= NMS_SEG_LDS candidates go to the block-cooperative NMS kernel
+    // segments of NMS_COOP_MIN < m <= NMS_SEG_LDS candidates go to the cooperative blocks of the NMS kernel
     if (!big)
         for (int c = c0; c < c1; ++c) {
             const int cnt = (c + 1 < C ? seg[c + 1] : (int)M) - seg[c];
@@ -484,10 +501,19 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
                 if (at < gridDim.x * (uint32_t)C) coop_list[at] = (int)(b * (uint32_t)C + (uint32_t)c);
             }
         }
-    for (uint32_t i = tid; i < M; i += PART_THREADS) {
-        const uint64_t k = in[i];
-        const uint32_t at = (uint32_t)atomicAdd(&s_hist[min(key_class(k), cmax)], 1);
-        if (at < M) out[at] = k;
+    if (in_regs) {
+#pragma unroll
+        for (int r = 0; r < PART_REG; ++r)
+            if (tid + (uint32_t)r * PART_THREADS < M) {
+                const uint32_t at = (uint32_t)atomicAdd(&s_hist[min(key_class(kreg[r]), cmax)], 1);
+                if (at < M) out[at] = kreg[r];
+            }
+    } else {
+        for (uint32_t i = tid; i < M; i += PART_THREADS) {
+            const uint64_t k = in[i];
+            const uint32_t at = (uint32_t)atomicAdd(&s_hist[min(key_class(k), cmax)], 1);
+            if (at < M) out[at] = k;
+        }
     }
     if (!big) return;                                    // block-uniform
     if (tid == 0) big_flag[b] = 1;
