@@ -43,15 +43,16 @@ def grid(cfg):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--cfg', type=int, nargs='*', default=[1, 2, 3, 4, 5, 6],
-                    help='1-5: BASELINE.json configs; 6: evaluation side (COCO matching) on the gathered cfg-5 batch')
+    ap.add_argument('--cfg', type=int, nargs='*', default=[1, 2, 3, 4, 5, 6, 7],
+                    help='1-5: BASELINE.json configs; 6: evaluation side (COCO matching) on the gathered cfg-5 batch; '
+                         '7: ground-truth preparation of a 64-image batch')
     ap.add_argument('--iters', type=int, default=20)
     args = ap.parse_args()
     lib = _lib.load()
     dev = _lib.require_gpu()
     st = _lib.stream_ptr()
     rows = []
-    for cfg in [x for x in args.cfg if x != 6]:
+    for cfg in [x for x in args.cfg if x <= 5]:
         c = workloads.CONFIGS[cfg]
         anchors = grid(cfg)
         N = anchors.shape[0]
@@ -144,6 +145,36 @@ def main():
                       (512, 512), C)
         row['cpu_oracle_img_s'] = n / (time.perf_counter() - t0)
         rows.append(row)
+    # ground-truth preparation, ragged annotations of 64 images -> [64,64,4] / [64,64]
+    if 7 in args.cfg:
+        import time
+        import numpy as np
+        from oracle import odbox_oracle as OO
+        rng = np.random.default_rng(1007)
+        B, max_items, S = 64, 64, 512
+        counts = rng.integers(5, 60, B)
+        hw = np.stack([rng.integers(300, 1200, B), rng.integers(300, 1200, B)], 1).astype(np.float32)
+        boxes = [np.stack([rng.uniform(0, 200, n), rng.uniform(0, 200, n), rng.uniform(8, 90, n), rng.uniform(8, 90, n)], 1).astype(np.float32) for n in counts]
+        labels = [rng.integers(0, 80, n).astype(np.int32) for n in counts]
+        offs = np.zeros(B + 1, np.int32)
+        np.cumsum(counts, out=offs[1:])
+        d_boxes = torch.as_tensor(np.concatenate(boxes)).to(dev)
+        d_lab = torch.as_tensor(np.concatenate(labels)).to(dev)
+        d_offs = torch.as_tensor(offs).to(dev)
+        d_hw = torch.as_tensor(hw).to(dev)
+        ob = torch.empty((B, max_items, 4), device=dev)
+        ol = torch.empty((B, max_items), dtype=torch.int32, device=dev)
+
+        def step():
+            rc = lib.odbox_gt_prepare_xywh(d_boxes.data_ptr(), d_lab.data_ptr(), d_offs.data_ptr(), d_hw.data_ptr(), B, max_items,
+                                           float(S), 0, 0, ob.data_ptr(), ol.data_ptr(), st)
+            assert rc == 0
+        t = event_time(step, args.iters)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            OO.padded_batch_boxes([OO.prepare_example_boxes(bb, ll, h, S, max_items) for bb, ll, h in zip(boxes, labels, hw)], max_items)
+        cpu = B * 20 / (time.perf_counter() - t0)
+        rows.append(dict(cfg='7_gt_prepare', B=B, rows=int(offs[-1]), us=t * 1e6, img_s=B / t, cpu_oracle_img_s=cpu))
     for r in rows:
         print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}))
 
