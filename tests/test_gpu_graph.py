@@ -68,3 +68,78 @@ def test_match_encode_and_decode_nms_replay_from_a_hip_graph():
         for a, b in zip(replayed, (out_reg, out_lab, det_b, det_s, det_l, det_k, det_n)):
             assert torch.equal(a, b)
         assert int(det_n.min()) > 0
+
+
+def test_loss_eval_and_gt_preparation_replay_from_a_hip_graph():
+    import ctypes
+    from object_detection_amd import cocoeval as CE
+    lib = _lib.load()
+    dev = _lib.require_gpu()
+    S, B, C, R, Gp = 256, 4, 12, 40, 32
+    anchors = torch.as_tensor(O.generate_anchors(S)).to(dev)
+    N = anchors.shape[0]
+
+    def inputs(seed):
+        r = np.random.default_rng(seed)
+        gts = [workloads.gt_boxes(r, S, 20, C, pad_to=Gp) for _ in range(B)]
+        ev = workloads.eval_inputs(B=B, R=R, G=Gp, C=C, S=S, seed=seed)
+        return dict(gt=np.stack([g[0] for g in gts]), lab=np.stack([g[1] for g in gts]),
+                    pb=r.normal(0, 1, (B, N, 4)).astype(np.float32), ps=r.uniform(0, 1, (B, N, C)).astype(np.float32),
+                    xywh=r.uniform(1, 90, (B * 20, 4)).astype(np.float32), xl=r.integers(0, C, B * 20).astype(np.int32), **ev)
+
+    first = inputs(1)
+    t = {k: torch.as_tensor(v).to(dev) for k, v in first.items()}
+    offs = torch.arange(0, B * 20 + 1, 20, dtype=torch.int32, device=dev)
+    hw = torch.tensor([[300., 400.]] * B, device=dev)
+    loss = torch.empty(4, device=dev)
+    gb, gs = torch.empty_like(t['pb']), torch.empty_like(t['ps'])
+    ws_loss = torch.empty(lib.odbox_match_loss_workspace(B, N), dtype=torch.uint8, device=dev)
+    p = CE.Params()
+    thr = np.ascontiguousarray(p.iouThrs, np.float64)
+    rng_ = np.ascontiguousarray(p.areaRng, np.float64)
+    dtm = torch.empty((B, 4, 10, R), dtype=torch.int32, device=dev)
+    dti = torch.empty((B, 4, 10, R), dtype=torch.uint8, device=dev)
+    gtm = torch.empty((B, 4, 10, Gp), dtype=torch.int32, device=dev)
+    gti = torch.empty((B, 4, Gp), dtype=torch.uint8, device=dev)
+    rank = torch.empty((B, R), dtype=torch.int32, device=dev)
+    ws_ev = torch.empty(lib.odbox_coco_match_workspace(B, R), dtype=torch.uint8, device=dev)
+    pb_out = torch.empty((B, 64, 4), device=dev)
+    pl_out = torch.empty((B, 64), dtype=torch.int32, device=dev)
+    outs = (loss, gb, gs, dtm, dti, gtm, gti, rank, pb_out, pl_out)
+
+    def enqueue():
+        st = _lib.stream_ptr()
+        rc = lib.odbox_match_loss(anchors.data_ptr(), t['gt'].data_ptr(), t['lab'].data_ptr(), B, N, Gp, C, float(S), float(S),
+                                  0.4, 0.5, t['pb'].data_ptr(), t['ps'].data_ptr(), 1.5, 0.25, 1.0, loss.data_ptr(),
+                                  gb.data_ptr(), gs.data_ptr(), ws_loss.data_ptr(), ws_loss.numel(), st)
+        assert rc == 0, lib.odbox_last_error()
+        rc = lib.odbox_coco_match(t['dt_boxes'].data_ptr(), t['dt_scores'].data_ptr(), t['dt_labels'].data_ptr(),
+                                  t['gt_boxes'].data_ptr(), t['gt_labels'].data_ptr(), B, R, Gp, C,
+                                  thr.ctypes.data_as(ctypes.c_void_p), 10, rng_.ctypes.data_as(ctypes.c_void_p), 4, 100,
+                                  dtm.data_ptr(), dti.data_ptr(), gtm.data_ptr(), gti.data_ptr(), rank.data_ptr(),
+                                  ws_ev.data_ptr(), ws_ev.numel(), st)
+        assert rc == 0, lib.odbox_last_error()
+        rc = lib.odbox_gt_prepare_xywh(t['xywh'].data_ptr(), t['xl'].data_ptr(), offs.data_ptr(), hw.data_ptr(), B, 64, 512.0,
+                                       0, 0, pb_out.data_ptr(), pl_out.data_ptr(), st)
+        assert rc == 0, lib.odbox_last_error()
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        enqueue()
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        enqueue()
+    for seed in (2, 3):
+        for k, v in inputs(seed).items():
+            t[k].copy_(torch.as_tensor(v))
+        graph.replay()
+        torch.cuda.synchronize()
+        replayed = [o.clone() for o in outs]
+        for o in outs:
+            o.fill_(3)
+        enqueue()
+        torch.cuda.synchronize()
+        for a, b in zip(replayed, outs):
+            assert torch.equal(a, b)
+        assert float(loss[2]) > 0 and int((dtm > 0).sum()) > 0
