@@ -1,0 +1,173 @@
+// odbox_c_check -- the C-ABI of libodbox.so driven from a plain host program: hipMalloc'd buffers,
+// a hipStream_t, no Python and no torch.  It is what a non-Python caller (a C++ data loader, a
+// serving loop) links against.  Checks both hot paths against the C restatement of the oracle
+// (oracle/odbox_oracle.c, test infrastructure) and prints PASS / FAIL.
+//
+//   hipcc --offload-arch=gfx950 -O2 -Iinclude tests/c_abi/odbox_c_check.cpp \
+//         -Lobject_detection_amd -lodbox -Loracle/_build -lodbox_oracle -o tests/c_abi/odbox_c_check
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "odbox.h"
+
+extern "C" {
+void odbox_oracle_anchor_tile(const float *base, int A, int fh, int fw, float stride, float *out);
+void odbox_oracle_match_encode(const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B, int N, int G,
+                               int C, float img_h, float img_w, float neg_thr, float pos_thr, float *out_regression,
+                               float *out_labels, int32_t *out_match_idx, int8_t *out_state, float *out_max_iou,
+                               int threads);
+int odbox_oracle_decode_nms(const float *anchors, const float *regress_or_boxes, const float *scores, int B, int N, int C,
+                            float img_h, float img_w, int do_clip, float score_thr, float iou_thr, int max_ret,
+                            float *out_boxes, float *out_scores, int32_t *out_labels, int32_t *out_keep_anchor,
+                            int32_t *out_count, int threads);
+}
+
+#define HIP_OK(x)                                                                     \
+    do {                                                                              \
+        hipError_t e_ = (x);                                                          \
+        if (e_ != hipSuccess) {                                                       \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                   \
+            return 2;                                                                 \
+        }                                                                             \
+    } while (0)
+#define ODBOX_OK(x)                                                                   \
+    do {                                                                              \
+        int rc_ = (x);                                                                \
+        if (rc_ != 0) {                                                               \
+            fprintf(stderr, "%s -> %d: %s\n", #x, rc_, odbox_last_error());           \
+            return 2;                                                                 \
+        }                                                                             \
+    } while (0)
+
+static uint32_t g_seed = 12345u;
+static float urand() { g_seed = g_seed * 1664525u + 1013904223u; return (float)(g_seed >> 8) * (1.0f / 16777216.0f); }
+
+template <typename T>
+static T *to_device(const std::vector<T> &h)
+{
+    T *d = nullptr;
+    if (hipMalloc((void **)&d, h.size() * sizeof(T) + 16) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return d;
+}
+template <typename T>
+static bool from_device(std::vector<T> &h, const T *d)
+{
+    return hipMemcpy(h.data(), d, h.size() * sizeof(T), hipMemcpyDeviceToHost) == hipSuccess;
+}
+static size_t mismatches(const float *a, const float *b, size_t n, float rtol)
+{
+    size_t bad = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const float d = fabsf(a[i] - b[i]);
+        if (!(d <= rtol * fabsf(b[i]) + 1e-6f)) ++bad;
+    }
+    return bad;
+}
+
+int main()
+{
+    if (odbox_version() != ODBOX_VERSION) { fprintf(stderr, "version mismatch\n"); return 2; }
+    hipStream_t st;
+    HIP_OK(hipStreamCreate(&st));
+
+    // ---- anchors: one 16 x 16 level, 9 anchors per cell, stride 8 (anchors.py:44-87) ------------
+    const int A = 9, F = 16, S = 128, N = F * F * A, B = 3, G = 12, C = 5;
+    std::vector<float> base(A * 4);
+    for (int a = 0; a < A; ++a) {
+        const float w = 16.0f + 6.0f * (float)(a % 3), h = w * (a / 3 == 0 ? 1.0f : (a / 3 == 1 ? 2.0f : 0.5f));
+        base[a * 4 + 0] = -w / 2; base[a * 4 + 1] = -h / 2; base[a * 4 + 2] = w / 2; base[a * 4 + 3] = h / 2;
+    }
+    std::vector<float> anchors_ref((size_t)N * 4), anchors((size_t)N * 4);
+    odbox_oracle_anchor_tile(base.data(), A, F, F, 8.0f, anchors_ref.data());
+    float *d_base = to_device(base), *d_anchors = nullptr;
+    HIP_OK(hipMalloc((void **)&d_anchors, anchors.size() * sizeof(float)));
+    ODBOX_OK(odbox_anchor_tile(d_base, A, F, F, 8.0f, d_anchors, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (!from_device(anchors, d_anchors)) return 2;
+    size_t bad = 0;
+    for (size_t i = 0; i < anchors.size(); ++i) bad += anchors[i] != anchors_ref[i];
+    printf("anchor_tile:  %zu of %zu values differ\n", bad, anchors.size());
+    size_t failures = bad;
+
+    // ---- match + encode (anchors.py:116-213) -----------------------------------------------------
+    std::vector<float> gt((size_t)B * G * 4);
+    std::vector<int32_t> lab((size_t)B * G);
+    for (int b = 0; b < B; ++b)
+        for (int g = 0; g < G; ++g) {
+            float *p = &gt[((size_t)b * G + g) * 4];
+            if (g >= 8) { p[0] = p[1] = p[2] = p[3] = -1.0f; lab[(size_t)b * G + g] = -1; continue; }   // padding
+            const float cx = urand() * S, cy = urand() * S, w = 8 + urand() * 40, h = 8 + urand() * 40;
+            p[0] = fmaxf(cx - w / 2, 0); p[1] = fmaxf(cy - h / 2, 0); p[2] = fminf(cx + w / 2, S - 1); p[3] = fminf(cy + h / 2, S - 1);
+            lab[(size_t)b * G + g] = (int32_t)(urand() * C) % C;
+        }
+    std::vector<float> reg((size_t)B * N * 5), lbl((size_t)B * N * (C + 1)), reg_ref(reg.size()), lbl_ref(lbl.size());
+    std::vector<int32_t> midx((size_t)B * N), midx_ref(midx.size());
+    std::vector<int8_t> state((size_t)B * N), state_ref(state.size());
+    odbox_oracle_match_encode(anchors_ref.data(), gt.data(), lab.data(), B, N, G, C, (float)S, (float)S, 0.4f, 0.5f,
+                              reg_ref.data(), lbl_ref.data(), midx_ref.data(), state_ref.data(), nullptr, 1);
+    float *d_gt = to_device(gt), *d_reg = nullptr, *d_lbl = nullptr;
+    int32_t *d_lab = to_device(lab), *d_midx = nullptr;
+    int8_t *d_state = nullptr;
+    HIP_OK(hipMalloc((void **)&d_reg, reg.size() * sizeof(float)));
+    HIP_OK(hipMalloc((void **)&d_lbl, lbl.size() * sizeof(float)));
+    HIP_OK(hipMalloc((void **)&d_midx, midx.size() * sizeof(int32_t)));
+    HIP_OK(hipMalloc((void **)&d_state, state.size()));
+    ODBOX_OK(odbox_match_encode(d_anchors, d_gt, d_lab, B, N, G, C, (float)S, (float)S, 0.4f, 0.5f, d_reg, d_lbl, d_midx,
+                                d_state, nullptr, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (!from_device(reg, d_reg) || !from_device(lbl, d_lbl) || !from_device(midx, d_midx) || !from_device(state, d_state)) return 2;
+    bad = 0;
+    size_t fg = 0;
+    for (size_t i = 0; i < midx.size(); ++i) { bad += midx[i] != midx_ref[i]; bad += state[i] != state_ref[i]; fg += state_ref[i] == 1; }
+    for (size_t i = 0; i < lbl.size(); ++i) bad += lbl[i] != lbl_ref[i];
+    const size_t bad_reg = mismatches(reg.data(), reg_ref.data(), reg.size(), 1e-5f);
+    printf("match_encode: %zu index/state/one-hot mismatches, %zu offsets beyond 1e-5 (%zu foreground anchors)\n", bad, bad_reg, fg);
+    failures += bad + bad_reg + (fg == 0);
+
+    // ---- decode + NMS (encoder.py:200-214, bndbox.py:117-252) ------------------------------------
+    const int max_ret = 20;
+    std::vector<float> rgs((size_t)B * N * 4), scores((size_t)B * N * C);
+    for (float &v : rgs) v = (urand() - 0.5f) * 2.0f;
+    for (size_t i = 0; i < scores.size(); ++i) scores[i] = urand() < 0.03f ? 0.3f + floorf(urand() * 64.0f) / 91.0f : urand() * 0.25f;
+    std::vector<float> ob((size_t)B * max_ret * 4), os((size_t)B * max_ret), ob_ref(ob.size()), os_ref(os.size());
+    std::vector<int32_t> ol((size_t)B * max_ret), ok((size_t)B * max_ret), oc(B), ol_ref(ol.size()), ok_ref(ok.size()), oc_ref(B);
+    if (odbox_oracle_decode_nms(anchors_ref.data(), rgs.data(), scores.data(), B, N, C, (float)S, (float)S, 1, 0.3f, 0.45f, max_ret,
+                                ob_ref.data(), os_ref.data(), ol_ref.data(), ok_ref.data(), oc_ref.data(), 1) != 0) return 2;
+    const size_t ws_bytes = odbox_decode_nms_workspace(B, N, C, max_ret, 0);
+    void *d_ws = nullptr;
+    HIP_OK(hipMalloc(&d_ws, ws_bytes));
+    float *d_rgs = to_device(rgs), *d_scores = to_device(scores), *d_ob = nullptr, *d_os = nullptr;
+    int32_t *d_ol = nullptr, *d_ok = nullptr, *d_oc = nullptr;
+    HIP_OK(hipMalloc((void **)&d_ob, ob.size() * sizeof(float)));
+    HIP_OK(hipMalloc((void **)&d_os, os.size() * sizeof(float)));
+    HIP_OK(hipMalloc((void **)&d_ol, ol.size() * sizeof(int32_t)));
+    HIP_OK(hipMalloc((void **)&d_ok, ok.size() * sizeof(int32_t)));
+    HIP_OK(hipMalloc((void **)&d_oc, oc.size() * sizeof(int32_t)));
+    ODBOX_OK(odbox_decode_nms(d_anchors, d_rgs, d_scores, B, N, C, (float)S, (float)S, 1, 0.3f, 0.45f, max_ret, 0, d_ob, d_os, d_ol,
+                              d_ok, d_oc, d_ws, ws_bytes, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (!from_device(ob, d_ob) || !from_device(os, d_os) || !from_device(ol, d_ol) || !from_device(ok, d_ok) || !from_device(oc, d_oc)) return 2;
+    bad = 0;
+    for (size_t i = 0; i < ok.size(); ++i) { bad += ok[i] != ok_ref[i]; bad += ol[i] != ol_ref[i]; bad += os[i] != os_ref[i]; }
+    for (int b = 0; b < B; ++b) bad += oc[b] != oc_ref[b];
+    const size_t bad_box = mismatches(ob.data(), ob_ref.data(), ob.size(), 1e-5f);
+    printf("decode_nms:   %zu keep/label/score/count mismatches, %zu boxes beyond 1e-5 (%d, %d, %d detections)\n", bad, bad_box,
+           oc_ref[0], oc_ref[1], oc_ref[2]);
+    failures += bad + bad_box + (oc_ref[0] == 0);
+
+    // ---- error convention: a bad call returns a code and a message, nothing is thrown ------------
+    const int rc = odbox_decode_nms(d_anchors, d_rgs, d_scores, B, N, C, (float)S, (float)S, 1, 0.3f, 0.45f, max_ret, 0, d_ob, d_os,
+                                    d_ol, d_ok, d_oc, d_ws, 16, st);
+    printf("error path:   rc %d (%s)\n", rc, odbox_last_error());
+    failures += rc != ODBOX_ENOSPC;
+
+    printf(failures == 0 ? "PASS\n" : "FAIL\n");
+    return failures == 0 ? 0 : 1;
+}
