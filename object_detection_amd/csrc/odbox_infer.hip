@@ -34,6 +34,7 @@ struct ScanGeom {
     int kfull;         // leading reads that are in range for every lane = C / (V * LPR)
     int steps;         // wave-steps per tile; rows per tile R = steps * (64 >> lpr_log2)
     uint32_t buf_floats;   // floats per LDS buffer (multiple of 4)
+    uint32_t stream;       // 1: nt loads (tensor far beyond the Infinity Cache)
     uint32_t tpi_magic;    // floor(2^32 / tiles_per_image) for the tile -> image division
 };
 
@@ -43,13 +44,22 @@ struct ScanGeom {
 // ours: one s_waitcnt vmcnt(0) before a buffer is read.  M0 = wave-uniform LDS byte address;
 // lane l lands at M0 + l * size.  (M0 is a reserved register; nothing else in these kernels
 // uses it.  s_nop covers the SALU-writes-M0 -> LDS-DMA hazard.)
-__device__ __forceinline__ void dma16(const float *g, uint32_t lds_byte)
+// `stream` (wave-uniform): the `nt` cache policy -- a score tensor far beyond the 256 MB Infinity
+// Cache is read once and should not be kept anywhere (config 5: 192 -> 176 us); a small one may
+// still sit in that cache from its producer, where nt loads were measured slower (loss kernel).
+__device__ __forceinline__ void dma16(const float *g, uint32_t lds_byte, bool stream)
 {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte), "v"(g) : "memory");
+    if (stream)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(lds_byte), "v"(g) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte), "v"(g) : "memory");
 }
-__device__ __forceinline__ void dma4(const float *g, uint32_t lds_byte)
+__device__ __forceinline__ void dma4(const float *g, uint32_t lds_byte, bool stream)
 {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_byte), "v"(g) : "memory");
+    if (stream)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off nt" ::"s"(lds_byte), "v"(g) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_byte), "v"(g) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_address(const void *p)
 {
@@ -58,19 +68,19 @@ __device__ __forceinline__ uint32_t lds_address(const void *p)
 
 // contiguous run of nfloat floats: HBM -> LDS image at byte address `lds`, linear
 template <int VEC>
-__device__ __forceinline__ void dma_tile(const float *src, uint32_t lds, uint32_t nfloat, uint32_t lane)
+__device__ __forceinline__ void dma_tile(const float *src, uint32_t lds, uint32_t nfloat, uint32_t lane, bool stream)
 {
     if constexpr (VEC == 4) {
         const uint32_t nvec = nfloat >> 2;
         uint32_t i = 0;
-        for (; i + WAVE <= nvec; i += WAVE) dma16(src + (size_t)(i + lane) * 4, lds + i * 16);
-        if (i + lane < nvec) dma16(src + (size_t)(i + lane) * 4, lds + i * 16);
+        for (; i + WAVE <= nvec; i += WAVE) dma16(src + (size_t)(i + lane) * 4, lds + i * 16, stream);
+        if (i + lane < nvec) dma16(src + (size_t)(i + lane) * 4, lds + i * 16, stream);
         const uint32_t done = nvec << 2;
-        if (done + lane < nfloat) dma4(src + done + lane, lds + done * 4);
+        if (done + lane < nfloat) dma4(src + done + lane, lds + done * 4, stream);
     } else {
         uint32_t i = 0;
-        for (; i + WAVE <= nfloat; i += WAVE) dma4(src + i + lane, lds + i * 4);
-        if (i + lane < nfloat) dma4(src + i + lane, lds + i * 4);
+        for (; i + WAVE <= nfloat; i += WAVE) dma4(src + i + lane, lds + i * 4, stream);
+        if (i + lane < nfloat) dma4(src + i + lane, lds + i * 4, stream);
     }
 }
 
@@ -159,9 +169,9 @@ __global__ __launch_bounds__(WAVE) void score_scan_kernel(
         const float *src = scores + ((size_t)b * N + n0) * (size_t)C;
         const uint32_t dst = lds_base + which * g.buf_floats * 4u;
         if (((uintptr_t)src & 15u) == 0)
-            dma_tile<4>(src, dst, rows * (uint32_t)C, lane);
+            dma_tile<4>(src, dst, rows * (uint32_t)C, lane, g.stream != 0);
         else
-            dma_tile<1>(src, dst, rows * (uint32_t)C, lane);
+            dma_tile<1>(src, dst, rows * (uint32_t)C, lane, g.stream != 0);
     };
 
     // Tiles are handed out by ticket counters: a workgroup that is not resident at launch finds
@@ -1101,7 +1111,7 @@ int scan_bank_conflict(int C, int V, int LL)
 
 ScanGeom scan_geometry(int C, int N)
 {
-    ScanGeom g;
+    ScanGeom g{};
     g.V = (C % 4 == 0) ? 4 : (C % 2 == 0) ? 2 : 1;
     const int nvec = C / g.V;
     // Lanes per row: as FEW as possible (fewest instructions per row: no cross-lane reduction,
@@ -1266,7 +1276,9 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
     }
 
     // kernel 1: score scan -> unordered candidate keys per image
-    const ScanGeom g = scan_geometry(C, N);
+    ScanGeom g = scan_geometry(C, N);
+    g.stream = (uint64_t)B * (uint64_t)N * (uint64_t)C * sizeof(float) > (512ull << 20) ? 1u : 0u;
+    if (const char *e = getenv("ODBOX_SCAN_STREAM")) g.stream = atoi(e) != 0;        // tuning aid
     int rc = g.V == 4 ? launch_scan<4>(scores, B, N, C, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, st)
            : g.V == 2 ? launch_scan<2>(scores, B, N, C, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, st)
                       : launch_scan<1>(scores, B, N, C, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, st);
