@@ -717,6 +717,76 @@ __device__ __forceinline__ void nms_wave_segment(
         }
     }
 
+    // ---- at most two chunks (every segment this path sorts itself when the cooperative blocks are
+    // on): the kept boxes of chunk 0 stay in the registers of their own lanes and are named by a
+    // 64-bit mask -- no copy into the kept-list registers, no LDS, ~28 instructions per kept box
+    if (!presorted && m <= 2u * WAVE && !(dbg & 3u)) {
+        auto fetch = [&](uint32_t i, uint64_t &key, float4 &nb, float &area) {
+            key = 0ull;
+            nb = make_float4(0.f, 0.f, 0.f, 0.f);
+            area = 0.0f;
+            if (i < m) {
+                key = m <= WAVE ? reg_key : sorted[i];
+                const float4 v = candidate_box(anchors, rb, b, N, key_anchor(key), do_clip, hi_x, hi_y);
+                nb = make_float4(fminf(v.x, v.z), fminf(v.y, v.w), fmaxf(v.x, v.z), fmaxf(v.y, v.w));
+                area = (nb.w - nb.y) * (nb.z - nb.x);
+            }
+        };
+        uint64_t key0, key1 = 0ull;
+        float4 nb0, nb1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float ar0, ar1 = 0.0f;
+        fetch(lane, key0, nb0, ar0);
+        if (m > WAVE) fetch(WAVE + lane, key1, nb1, ar1);                 // both gathers in flight together
+        unsigned long long kmask0 = 0ull, kmask1 = 0ull;
+        int kept = 0;
+        unsigned long long mask = __ballot(lane < m);
+        while (mask != 0ull && kept < max_ret) {
+            const int j = __ffsll(mask) - 1;
+            kmask0 |= 1ull << j;
+            ++kept;
+            const bool hit = nms_suppresses(nb0, ar0, bcast_lane(nb0.x, j), bcast_lane(nb0.y, j), bcast_lane(nb0.z, j),
+                                            bcast_lane(nb0.w, j), bcast_lane(ar0, j), thr);
+            mask &= ~(__ballot(hit) | ((2ull << j) - 1ull));              // lanes <= j are decided
+        }
+        if (m > WAVE && kept < max_ret) {
+            bool hit = false, band = false;
+            for (unsigned long long km = kmask0; km != 0ull; km &= km - 1ull) {
+                const int j = __ffsll(km) - 1;
+                nms_test(nb1, ar1, bcast_lane(nb0.x, j), bcast_lane(nb0.y, j), bcast_lane(nb0.z, j), bcast_lane(nb0.w, j),
+                         bcast_lane(ar0, j), thr, hit, band);
+            }
+            if (__ballot(band && !hit) != 0ull)                           // wave-uniform, practically never
+                for (unsigned long long km = kmask0; km != 0ull; km &= km - 1ull) {
+                    const int j = __ffsll(km) - 1;
+                    if (nms_suppresses_exact(nb1, ar1, bcast_lane(nb0.x, j), bcast_lane(nb0.y, j), bcast_lane(nb0.z, j),
+                                             bcast_lane(nb0.w, j), bcast_lane(ar0, j), thr))
+                        hit = true;
+                }
+            mask = __ballot(WAVE + lane < m && !hit);
+            while (mask != 0ull && kept < max_ret) {
+                const int j = __ffsll(mask) - 1;
+                kmask1 |= 1ull << j;
+                ++kept;
+                const bool h1 = nms_suppresses(nb1, ar1, bcast_lane(nb1.x, j), bcast_lane(nb1.y, j), bcast_lane(nb1.z, j),
+                                               bcast_lane(nb1.w, j), bcast_lane(ar1, j), thr);
+                mask &= ~(__ballot(h1) | ((2ull << j) - 1ull));
+            }
+        }
+        int base = 0;
+        if (lane == 0) base = atomicAdd(fin_count + b * CNT_STRIDE, kept);
+        base = __shfl(base, 0);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if ((kmask0 >> lane) & 1ull) {
+            const uint32_t pos = (uint32_t)(base + __popcll(kmask0 & below));
+            if (pos < fin_stride) fin_keys[(size_t)b * fin_stride + pos] = cand_to_final(key0);
+        }
+        if ((kmask1 >> lane) & 1ull) {
+            const uint32_t pos = (uint32_t)(base + __popcll(kmask0) + __popcll(kmask1 & below));
+            if (pos < fin_stride) fin_keys[(size_t)b * fin_stride + pos] = cand_to_final(key1);
+        }
+        return;
+    }
+
     // kept boxes 0..127: lane k & 63 of set A (k < 64) or set B
     float ax0 = 0.f, ay0 = 0.f, ax1 = 0.f, ay1 = 0.f, aa = 0.f;
     float bx0 = 0.f, by0 = 0.f, bx1 = 0.f, by1 = 0.f, ba = 0.f;
@@ -854,6 +924,9 @@ __device__ __forceinline__ void nms_coop_block(
         const int start = seg_start[(size_t)b * (C + 1) + c];
         const uint32_t m = min((uint32_t)max(seg_start[(size_t)b * (C + 1) + c + 1] - start, 0), NMS_SEG_LDS);   // NMS_COOP_MIN < m <= NMS_SEG_LDS
         const uint32_t nw = (m + WAVE - 1) / WAVE;
+        // waves without a chunk leave at once when this block has no further item: their slots go to
+        // the per-wave blocks waiting behind (terminated waves do not count at the barriers)
+        if (items <= (int)nblocks && wave >= nw) return;
 
         // (1) rank sort: keys are distinct (the anchor id is part of the key), so the number of smaller
         // keys is the sorted position -- m broadcast LDS reads per thread and one barrier instead of
