@@ -140,3 +140,51 @@ def test_oracle_is_not_imported_by_the_product():
             if f.endswith(('.py', '.hip', '.h')):
                 text = open(os.path.join(dirpath, f)).read()
                 assert 'import oracle' not in text and 'from oracle' not in text and 'oracle/' not in text.replace('oracle/_', ''), f
+
+
+def test_every_entry_rejects_bad_arguments_without_touching_the_gpu(lib):
+    """Return-code convention of include/odbox.h: ODBOX_EINVAL (-1) / ODBOX_ENOSPC (-3) with a
+    message, decided on the host before any HIP call -- so this runs without a GPU."""
+    import ctypes
+    buf = (ctypes.c_float * 64)()                        # a host buffer: never dereferenced by these calls
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    odd = ctypes.c_void_p(p.value + 4)                   # 4-byte aligned only
+    thr = (ctypes.c_double * 2)(0.5, 0.75)
+    rng = (ctypes.c_double * 2)(0.0, 1e10)
+    cases = [
+        ('odbox_anchor_tile', (None, 9, 4, 4, 8.0, p, None), -1),
+        ('odbox_anchor_tile', (p, -1, 4, 4, 8.0, p, None), -1),
+        ('odbox_match_encode', (p, p, p, 1, 4, 2, 0, 8.0, 8.0, 0.4, 0.5, p, p, None, None, None, None), -1),      # C < 1
+        ('odbox_match_encode', (odd, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, None, None, None, None), -1),    # alignment
+        ('odbox_match_encode', (p, p, None, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, None, None, None, None), -1),   # labels needed
+        ('odbox_match_loss', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, p, p, None, p, 1 << 20, None), -1),   # one gradient only
+        ('odbox_match_loss', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, p, None, None, p, 4, None), -3),        # workspace
+        ('odbox_focal_loss', (p, p, 16, 1.5, 0.25, None, None, p, 1 << 20, None), -1),
+        ('odbox_focal_loss', (p, p, 16, 1.5, 0.25, p, None, p, 1, None), -3),
+        ('odbox_bbox_overlap', (None, p, 1, 4, 2, 0, p, None), -1),
+        ('odbox_bbox_transform', (p, 0, None, 1, 4, p, None), -1),
+        ('odbox_regress_boxes', (p, 0, p, 1, 4, None, None), -1),
+        ('odbox_clip_boxes', (None, 4, 8.0, 8.0, p, None), -1),
+        ('odbox_scale_boxes', (p, 4, 1.0, 1.0, 0, None, None), -1),
+        ('odbox_decode_nms', (p, p, p, 1, 4, 5000, 8.0, 8.0, 1, 0.3, 0.45, 100, 0, p, p, p, None, None, p, 1 << 30, None), -1),   # C over the key limit
+        ('odbox_decode_nms', (p, p, p, 1, 4, 2, 8.0, 8.0, 1, 0.3, 0.45, 100, 0, p, p, p, None, None, p, 16, None), -3),
+        ('odbox_decode_nms', (p, p, p, 1, 4, 2, 8.0, 8.0, 1, 0.3, 0.45, 100, -1, p, p, p, None, None, p, 1 << 30, None), -1),
+        ('odbox_coco_records', (None, 4, p, None, None, None), -1),
+        ('odbox_coco_iou', (p, None, 1, 2, 2, p, None), -1),
+        ('odbox_coco_match', (p, p, p, p, p, 1, 2, 2, 3, thr, 2, rng, 1, 100, p, p, None, None, p, p, 4, None), -3),
+        ('odbox_coco_match', (p, p, p, p, p, 1, 2, 2, 3, thr, 99, rng, 1, 100, p, p, None, None, p, p, 1 << 20, None), -1),     # too many thresholds
+        ('odbox_coco_match', (p, p, p, p, p, 1, 2, 5000, 3, thr, 2, rng, 1, 100, p, p, None, None, p, p, 1 << 20, None), -1),   # G over the limit
+        ('odbox_gt_prepare_xywh', (p, p, None, p, 2, 4, 512.0, 0, 0, p, p, None), -1),
+        ('odbox_gt_prepare_poly', (p, p, p, p, 2, 4, 512.0, 0, 7, p, p, None), -1),                                              # mode
+        ('odbox_gt_prepare_xywh', (p, p, p, p, 2, 4, 0.0, 0, 0, p, p, None), -1),                                                # image_size
+    ]
+    for name, args, want in cases:
+        rc = getattr(lib, name)(*args)
+        assert rc == want, (name, rc, lib.odbox_last_error())
+        assert name.encode() in lib.odbox_last_error(), (name, lib.odbox_last_error())
+    # empty problems are successes, decided before any pointer is looked at
+    assert lib.odbox_anchor_tile(None, 9, 0, 4, 8.0, None, None) == 0
+    assert lib.odbox_clip_boxes(None, 0, 8.0, 8.0, None, None) == 0
+    assert lib.odbox_decode_nms(None, None, None, 0, 4, 2, 8.0, 8.0, 1, 0.3, 0.45, 100, 0, None, None, None, None, None, None, 0, None) == 0
+    assert lib.odbox_coco_match(None, None, None, None, None, 0, 2, 2, 3, thr, 2, rng, 1, 100, None, None, None, None, None, None, 0, None) == 0
+    assert lib.odbox_gt_prepare_xywh(None, None, None, None, 0, 4, 512.0, 0, 0, None, None, None) == 0
