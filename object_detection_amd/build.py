@@ -35,11 +35,13 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get('HIPCC', 'hipcc')
+    # ODBOX_TUNING_HOOKS=1: the library reads the ODBOX_SCAN_* / ODBOX_NMS_DBG experiment knobs (tools/exp_*.sh)
+    hooks = ['-DODBOX_TUNING_HOOKS'] if os.environ.get('ODBOX_TUNING_HOOKS') == '1' else []
     os.makedirs(OBJ, exist_ok=True)
     objs = []
     for unit, extra in UNITS.items():
         obj = os.path.join(OBJ, unit.replace('.hip', '.o'))
-        cmd = [hipcc] + COMMON + extra + ['-c', os.path.join(CSRC, unit), '-o', obj]
+        cmd = [hipcc] + COMMON + extra + hooks + ['-c', os.path.join(CSRC, unit), '-o', obj]
         if verbose:
             print(' '.join(cmd))
         subprocess.run(cmd, check=True)

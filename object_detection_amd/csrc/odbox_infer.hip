@@ -1131,6 +1131,19 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
 // ------------------------------------------------------------------------------------------
 // workspace layout + launch geometry of odbox_decode_nms
 // ------------------------------------------------------------------------------------------
+// Tuning and experiment hooks (ODBOX_SCAN_*, ODBOX_NMS_DBG; used by tools/exp_*.sh) are read from
+// the environment only in a build made with ODBOX_TUNING_HOOKS=1 (object_detection_amd/build.py);
+// some of them switch parts of a kernel off, so a product build must not look at them.
+static inline const char *tuning_env(const char *name)
+{
+#ifdef ODBOX_TUNING_HOOKS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 struct NmsLayout {
     size_t off_counts, off_tickets, off_seg, off_coop, off_keys_a, off_keys_b, off_fin, total;
     uint32_t cand_stride, fin_stride;
@@ -1207,7 +1220,7 @@ ScanGeom scan_geometry(int C, int N)
         }
     }
     g.lpr_log2 = pick;
-    if (const char *e = getenv("ODBOX_SCAN_LPR_LOG2")) g.lpr_log2 = atoi(e) >= 0 && atoi(e) <= 6 ? atoi(e) : g.lpr_log2;
+    if (const char *e = tuning_env("ODBOX_SCAN_LPR_LOG2")) g.lpr_log2 = atoi(e) >= 0 && atoi(e) <= 6 ? atoi(e) : g.lpr_log2;
     const int lpr = 1 << g.lpr_log2;
     g.K = (nvec + lpr - 1) / lpr;
     g.kfull = nvec / lpr;
@@ -1216,7 +1229,7 @@ ScanGeom scan_geometry(int C, int N)
     int steps = (int)((12 * 1024) / step_bytes);                       // ~12 KiB per tile
     const int max_steps = (int)SCAN_MAX_ROWS / rows_per_step;
     g.steps = steps < 1 ? 1 : (steps > max_steps ? max_steps : steps);
-    if (const char *e = getenv("ODBOX_SCAN_STEPS")) g.steps = atoi(e) > 0 ? atoi(e) : g.steps;
+    if (const char *e = tuning_env("ODBOX_SCAN_STEPS")) g.steps = atoi(e) > 0 ? atoi(e) : g.steps;
     if (g.steps > max_steps) g.steps = max_steps;
     g.buf_floats = (uint32_t)align_up((size_t)g.steps * rows_per_step * C, 4);
     const uint32_t R = (uint32_t)g.steps * rows_per_step;
@@ -1261,10 +1274,10 @@ int launch_scan_inst(const float *scores, int B, int N, int C, const ScanGeom &g
         return fail(ODBOX_EINVAL, "odbox_decode_nms: C=%d needs %zu bytes of LDS per wave", C, lds);
     int per_cu = (int)((160 * 1024) / align_up(lds, 1024));
     per_cu = per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu);
-    if (const char *e = getenv("ODBOX_SCAN_WAVES_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;   // tuning aid
+    if (const char *e = tuning_env("ODBOX_SCAN_WAVES_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;   // tuning aid
     uint32_t nq = SCAN_QUEUES, dbg = 0;
-    if (const char *e = getenv("ODBOX_SCAN_QUEUES")) nq = atoi(e) > 0 && atoi(e) <= (int)SCAN_QUEUES ? atoi(e) : nq;
-    if (const char *e = getenv("ODBOX_SCAN_DBG")) dbg = (uint32_t)atoi(e);
+    if (const char *e = tuning_env("ODBOX_SCAN_QUEUES")) nq = atoi(e) > 0 && atoi(e) <= (int)SCAN_QUEUES ? atoi(e) : nq;
+    if (const char *e = tuning_env("ODBOX_SCAN_DBG")) dbg = (uint32_t)atoi(e);
     const uint64_t resident = (uint64_t)device_cu_count() * per_cu;
     const uint32_t grid = (uint32_t)(total < resident ? total : resident);
     if (int rc = allow_lds(score_scan_kernel<V, LL>, lds)) return rc;
@@ -1351,7 +1364,7 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
     // kernel 1: score scan -> unordered candidate keys per image
     ScanGeom g = scan_geometry(C, N);
     g.stream = (uint64_t)B * (uint64_t)N * (uint64_t)C * sizeof(float) > (512ull << 20) ? 1u : 0u;
-    if (const char *e = getenv("ODBOX_SCAN_STREAM")) g.stream = atoi(e) != 0;        // tuning aid
+    if (const char *e = tuning_env("ODBOX_SCAN_STREAM")) g.stream = atoi(e) != 0;        // tuning aid
     int rc = g.V == 4 ? launch_scan<4>(scores, B, N, C, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, st)
            : g.V == 2 ? launch_scan<2>(scores, B, N, C, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, st)
                       : launch_scan<1>(scores, B, N, C, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, st);
@@ -1399,7 +1412,7 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
                        (const float4 *)regress_or_boxes, N, C, do_clip, hi_x, hi_y, nms_thr, max_ret, nms_keys,
                        L.cand_stride, seg_start, big_flag, (const int *)coop_count, (const int *)coop_list, coop_blocks,
                        fin_count, fin_keys, L.fin_stride, (uint32_t)segs, waves, (uint32_t)per_wave, sort_cap,
-                       (uint32_t)(getenv("ODBOX_NMS_DBG") ? atoi(getenv("ODBOX_NMS_DBG")) : 0));
+                       (uint32_t)(tuning_env("ODBOX_NMS_DBG") ? atoi(tuning_env("ODBOX_NMS_DBG")) : 0));
     if (int r3 = launch_status("nms")) return r3;
 
     // kernel 4: final order, top max_ret, zero padding

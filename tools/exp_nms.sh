@@ -1,3 +1,4 @@
+# needs a library built with ODBOX_TUNING_HOOKS=1 (python -m object_detection_amd.build --force), see odbox_infer.hip tuning_env()
 # NMS kernel time with one of its two paths switched off (ODBOX_NMS_DBG 4: no cooperative blocks, 8: no wave blocks)
 cd /tmp && export TMPDIR=/tmp
 for d in 0 4 8; do

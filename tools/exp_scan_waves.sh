@@ -1,3 +1,4 @@
+# needs a library built with ODBOX_TUNING_HOOKS=1 (python -m object_detection_amd.build --force), see odbox_infer.hip tuning_env()
 # score-scan time against resident waves per CU (LDS left for other kernels)
 cd /tmp && export TMPDIR=/tmp
 for w in 3 4 5 6; do

@@ -1,4 +1,5 @@
-"""score-scan cache policy against tensor size: decode+NMS time with nt loads forced off / on."""
+"""score-scan cache policy against tensor size: decode+NMS time with nt loads forced off / on
+(needs a library built with ODBOX_TUNING_HOOKS=1, see odbox_infer.hip tuning_env())."""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
