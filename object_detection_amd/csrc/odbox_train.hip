@@ -76,6 +76,7 @@ __device__ __forceinline__ float pair_iou(const float4 a, float a_area, const fl
 //            the packed word.  This is the HBM-bound part: 4(C+1)+20 of the 4(C+1)+36 bytes.
 // ------------------------------------------------------------------------------------------
 constexpr int ME_TILE = 256;
+constexpr int ME_TILE_STREAM = 128;      // match_encode with a dense output far beyond the Infinity Cache
 constexpr int ME_GCHUNK = 512;
 
 // Phases 1 and 2 of the matcher for the calling thread's anchor n0 + threadIdx.x of image b:
@@ -90,6 +91,7 @@ struct TileMatch {
     bool live;         // n < N
 };
 
+template <int TILE>
 __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ anchors,
                                                 const float4 *__restrict__ gt_boxes,
                                                 const int32_t *__restrict__ gt_labels, uint32_t b, uint32_t n0, int N,
@@ -97,7 +99,7 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
 {
     __shared__ float4 s_gt[ME_GCHUNK];
     __shared__ float2 s_ga[ME_GCHUNK];          // (area, 1.0 if padded row else 0.0)
-    __shared__ uint16_t s_list[ME_TILE / WAVE][ME_GCHUNK];   // per wave: GT rows it must evaluate
+    __shared__ uint16_t s_list[TILE / WAVE][ME_GCHUNK];      // per wave: GT rows it must evaluate
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const uint32_t n = n0 + tid;
@@ -131,7 +133,7 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
     for (int g0 = 0; g0 < G; g0 += ME_GCHUNK) {
         const int cnt = min(ME_GCHUNK, G - g0);
         if (g0) __syncthreads();
-        for (int g = tid; g < cnt; g += ME_TILE) {
+        for (int g = tid; g < cnt; g += TILE) {
             float4 gb = gtb[g0 + g];
             float area = (gb.w - gb.y) * (gb.z - gb.x);                  // bndbox.py:286
             float gmax = fmaxf(fmaxf(gb.x, gb.y), fmaxf(gb.z, gb.w));    // bndbox.py:295
@@ -204,26 +206,29 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
 // STREAM: the dense labels leave through cache-bypassing stores.  Measured: outputs that fit the
 // 256 MB Infinity Cache (cfg 2: 234 MB) are 1.5x FASTER with plain stores (40 vs 63 us), outputs
 // far beyond it (cfg 3: 2.2 GB per GPU) 6 % faster bypassing it (364 vs 387 us; `sc1 nt`, plain `nt` 372).
+// The streaming variant also runs 128-anchor tiles (364 -> 360 us on cfg 3); the small launches
+// prefer 256 (cfg 2: 40 us vs 45 us with 128, 41 us with 512).
 template <bool STREAM>
-__global__ __launch_bounds__(ME_TILE) void match_encode_kernel(
+__global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE) void match_encode_kernel(
     const float4 *__restrict__ anchors, const float4 *__restrict__ gt_boxes,
     const int32_t *__restrict__ gt_labels, int N, int G, int C, float img_h, float img_w,
     float neg_thr, float pos_thr, float *__restrict__ out_reg, float *__restrict__ out_lab,
     int32_t *__restrict__ out_idx, int8_t *__restrict__ out_state, float *__restrict__ out_iou,
     uint32_t tiles_per_image, uint32_t d_magic)
 {
-    __shared__ float s_reg[ME_TILE * 5];
-    __shared__ uint32_t s_ls[ME_TILE];          // (label + 1) | (state + 1) << 16
+    constexpr int TILE = STREAM ? ME_TILE_STREAM : ME_TILE;
+    __shared__ float s_reg[TILE * 5];
+    __shared__ uint32_t s_ls[TILE];          // (label + 1) | (state + 1) << 16
 
     const uint32_t tid = threadIdx.x;
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t b = blk / tiles_per_image;
-    const uint32_t n0 = (blk - b * tiles_per_image) * ME_TILE;
+    const uint32_t n0 = (blk - b * tiles_per_image) * TILE;
     const uint32_t n = n0 + tid;
     const bool live = n < (uint32_t)N;
-    const uint32_t tile_n = min((uint32_t)ME_TILE, (uint32_t)N - n0);
+    const uint32_t tile_n = min((uint32_t)TILE, (uint32_t)N - n0);
 
-    const TileMatch tm = match_tile(anchors, gt_boxes, gt_labels, b, n0, N, G, C, img_h, img_w, neg_thr, pos_thr);
+    const TileMatch tm = match_tile<TILE>(anchors, gt_boxes, gt_labels, b, n0, N, G, C, img_h, img_w, neg_thr, pos_thr);
     const float4 a = tm.a;
     const float best_iou = tm.best_iou;
     const int best = tm.best, state = tm.state, label = tm.label;
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(ME_TILE) void match_encode_kernel(
         const uint32_t head = min(count, (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) >> 2);
         const uint32_t nvec = (count - head) >> 2;
         if (tid < head) p[tid] = s_reg[tid];
-        for (uint32_t v = tid; v < nvec; v += ME_TILE) {
+        for (uint32_t v = tid; v < nvec; v += TILE) {
             const uint32_t e = head + 4 * v;
             *reinterpret_cast<float4 *>(p + e) = make_float4(s_reg[e], s_reg[e + 1], s_reg[e + 2], s_reg[e + 3]);
         }
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(ME_TILE) void match_encode_kernel(
             divmod_u32(tid, d, d_magic, q, r);
             p[tid] = element(s_ls[q], r);
         }
-        for (uint32_t v = tid; v < nvec; v += ME_TILE) {
+        for (uint32_t v = tid; v < nvec; v += TILE) {
             const uint32_t e = head + 4 * v;
             uint32_t q, r;
             divmod_u32(e, d, d_magic, q, r);
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(ME_TILE) void match_encode_kernel(
                 if (++r == d) {
                     r = 0;
                     ++q;
-                    ls = s_ls[min(q, (uint32_t)ME_TILE - 1)];
+                    ls = s_ls[min(q, (uint32_t)TILE - 1)];
                 }
             }
             if (STREAM) {
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     v4f cur = {0.5f, 0.5f, 0.5f, 0.5f};
     if (d >= 4 && nvec) cur = pv4[min(tid, nvec - 1)];
 
-    const TileMatch tm = match_tile(anchors, gt_boxes, gt_labels, b, n0, N, G, C, img_h, img_w, neg_thr, pos_thr);
+    const TileMatch tm = match_tile<ME_TILE>(anchors, gt_boxes, gt_labels, b, n0, N, G, C, img_h, img_w, neg_thr, pos_thr);
     s_live[tid] = tm.live && tm.state != -1 ? 1.0f : 0.0f;
 
     // the one y = 1 element of a foreground anchor: fetch it now, correct the sum after the stream
@@ -729,15 +734,16 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
     if (!aligned16(anchors) || !aligned16(gt_boxes))
         return fail(ODBOX_EINVAL, "odbox_match_encode: anchors / gt_boxes must be 16-byte aligned");
     if (B == 0 || N == 0) return 0;
-    const uint64_t tiles = ((uint64_t)N + ME_TILE - 1) / ME_TILE;
-    const uint64_t blocks = tiles * (uint64_t)B;
-    if (blocks > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_match_encode: grid too large");
     const uint32_t d = (uint32_t)C + 1u;
     const uint32_t magic = d == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / d);
-    // dense labels beyond twice the 256 MB Infinity Cache: bypass it (see match_encode_kernel)
+    // dense labels beyond twice the 256 MB Infinity Cache: bypass it, smaller tiles (see match_encode_kernel)
     const bool stream_out = out_labels && (uint64_t)B * (uint64_t)N * d * sizeof(float) > (512ull << 20);
+    const int tile = stream_out ? ME_TILE_STREAM : ME_TILE;
+    const uint64_t tiles = ((uint64_t)N + tile - 1) / tile;
+    const uint64_t blocks = tiles * (uint64_t)B;
+    if (blocks > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_match_encode: grid too large");
     auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(ME_TILE), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(tile), 0, (hipStream_t)stream,
                            (const float4 *)anchors, (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w,
                            neg_thr, pos_thr, out_regression, out_labels, out_match_idx, out_state, out_max_iou,
                            (uint32_t)tiles, magic);
