@@ -217,3 +217,36 @@ def test_bad_arguments_raise():
         A.anchor_targets_bbox(np.zeros((4, 3), F), (1, 8, 8, 3), np.zeros((1, 2, 4), F), np.zeros((1, 2), np.int32), 2)
     with pytest.raises(OdboxError):
         A.match_encode(np.zeros((4, 4), F), (8, 8), np.zeros((1, 2, 4), F), np.zeros((1, 2), np.int32), 5000)
+
+
+@pytest.mark.parametrize('C,N,off', [(1, 257, 1), (2, 300, 2), (3, 511, 3), (5, 1000, 1), (80, 333, 1), (81, 777, 3), (90, 1025, 2)])
+def test_unaligned_dense_outputs_and_odd_shapes(C, N, off):
+    """The dense outputs are written with 16-byte stores over the flat element range plus scalar
+    head / tail stores: output tensors that start 4, 8 or 12 bytes into an allocation, odd anchor
+    counts and odd row lengths (C + 1) must land exactly like the oracle's."""
+    from object_detection_amd import _lib
+    lib = _lib.load()
+    dev = torch.device('cuda')
+    rng = np.random.default_rng(C * 1000 + N)
+    B, G, S = 3, 7, 200
+    anchors = O.tile_anchors(O.base_anchors(32, (1, 2, .5)), 12, 12, 16)[:N] if N <= 1296 else None
+    gts = [workloads.gt_boxes(rng, S, G, C, pad_to=G + 2) for _ in range(B)]
+    gt = np.stack([g[0] for g in gts])
+    lab = np.stack([g[1] for g in gts])
+    a = torch.as_tensor(anchors).to(dev)
+    g_ = torch.as_tensor(gt).to(dev)
+    l_ = torch.as_tensor(lab).to(dev)
+    reg_buf = torch.full((B * N * 5 + 8,), 7.0, device=dev)
+    lab_buf = torch.full((B * N * (C + 1) + 8,), 7.0, device=dev)
+    reg = reg_buf[off:off + B * N * 5]
+    out = lab_buf[off:off + B * N * (C + 1)]
+    rc = lib.odbox_match_encode(a.data_ptr(), g_.data_ptr(), l_.data_ptr(), B, N, G + 2, C, float(S), float(S), 0.4, 0.5,
+                                reg.data_ptr(), out.data_ptr(), None, None, None, _lib.stream_ptr())
+    assert rc == 0, lib.odbox_last_error()
+    ref = c_oracle.match_encode(anchors, (S, S), gt, lab, C, threads=4)
+    np.testing.assert_array_equal(cpu(out).reshape(B, N, C + 1), ref['labels'])
+    with np.errstate(invalid='ignore'):
+        np.testing.assert_allclose(cpu(reg).reshape(B, N, 5), ref['regression'], rtol=RTOL, atol=0, equal_nan=True)
+    # nothing outside the views was touched
+    assert float(reg_buf[:off].min()) == 7.0 and float(reg_buf[off + B * N * 5:].min()) == 7.0
+    assert float(lab_buf[:off].min()) == 7.0 and float(lab_buf[off + B * N * (C + 1):].min()) == 7.0

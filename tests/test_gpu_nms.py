@@ -235,3 +235,44 @@ def test_cooperative_block_with_mixed_segments_in_one_image():
     got = BB.decode_and_nms(anchors, regress, scores, (160, 160), max_ret=100, return_keep=True)
     want = c_oracle.decode_nms(anchors, regress, scores, (160, 160), max_ret=100, threads=4)
     check(got, want)
+
+
+@pytest.mark.parametrize('C', [1, 2, 3, 4, 5, 6, 8, 12, 16, 17, 31, 32, 33, 48, 64, 65, 91, 100, 128, 200, 256, 384, 1000, 4096])
+def test_class_counts_exercise_every_scan_geometry(C):
+    """The score scan picks its read width (1 / 2 / 4 floats), lanes per row and tile height from C;
+    sweep C (and odd anchor counts, unaligned score rows) against the C oracle."""
+    rng = np.random.default_rng(1000 + C)
+    N = int(rng.integers(300, 1400)) | 1                                  # odd: rows end off any vector boundary
+    B = 2 if C < 1000 else 1
+    hot = min(N // 2, 250)
+    anchors, regress, scores = _case(rng, B, N, C, hot)
+    got = BB.decode_and_nms(anchors, regress, scores, (160, 160), max_ret=50, return_keep=True)
+    want = c_oracle.decode_nms(anchors, regress, scores, (160, 160), max_ret=50, threads=4)
+    check(got, want)
+    assert want[4].min() > 0
+
+
+def test_unaligned_score_and_box_views():
+    """Scores that start 4 bytes into an allocation (the API asks for 4-byte alignment of scores only)."""
+    rng = np.random.default_rng(99)
+    anchors, regress, scores = _case(rng, 2, 901, 90, 300)
+    dev = torch.device('cuda')
+    flat = torch.empty(scores.size + 1, dtype=torch.float32, device=dev)
+    view = flat[1:].view(scores.shape)
+    view.copy_(torch.as_tensor(scores))
+    assert view.data_ptr() % 16 == 4
+    from object_detection_amd import _lib
+    lib = _lib.load()
+    a = torch.as_tensor(anchors).to(dev)
+    r = torch.as_tensor(regress).to(dev)
+    ob = torch.empty((2, 100, 4), device=dev)
+    os_ = torch.empty((2, 100), device=dev)
+    ol = torch.empty((2, 100), dtype=torch.int32, device=dev)
+    ok = torch.empty((2, 100), dtype=torch.int32, device=dev)
+    oc = torch.empty((2,), dtype=torch.int32, device=dev)
+    ws = torch.empty(lib.odbox_decode_nms_workspace(2, 901, 90, 100, 0), dtype=torch.uint8, device=dev)
+    rc = lib.odbox_decode_nms(a.data_ptr(), r.data_ptr(), view.data_ptr(), 2, 901, 90, 160.0, 160.0, 1, 0.3, 0.45, 100, 0,
+                              ob.data_ptr(), os_.data_ptr(), ol.data_ptr(), ok.data_ptr(), oc.data_ptr(), ws.data_ptr(),
+                              ws.numel(), _lib.stream_ptr())
+    assert rc == 0, lib.odbox_last_error()
+    check((ob, os_, ol, ok, oc), c_oracle.decode_nms(anchors, regress, scores, (160, 160), threads=4))
