@@ -79,6 +79,21 @@ int odbox_match_loss(const float *anchors /*[N,4]*/, const float *gt_boxes /*[B,
                      float *grad_boxes /*[B,N,4] or NULL*/, float *grad_scores /*[B,N,C] or NULL*/,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* The backward pass of the same losses for autograd-style callers (what tf.GradientTape does to
+ * metric.py:97-123 in train.py): grad_boxes = grad_scale[0] * d dist_sum / d pred_boxes,
+ * grad_scores = grad_scale[1] * d class_sum / d pred_scores.  grad_scale is two floats in DEVICE
+ * memory -- typically upstream_gradient / npos, computed on the device from out_loss[2] -- so the
+ * normaliser never visits the host and the [B,N,C] gradient is written once, already final.  The
+ * match is recomputed from the same inputs (cheaper than saving it: the kernel is bound by the
+ * score stream).  No workspace; same alignment rules as odbox_match_loss. */
+int odbox_match_loss_backward(const float *anchors /*[N,4]*/, const float *gt_boxes /*[B,G,4]*/,
+                              const int32_t *gt_labels /*[B,G]*/, int B, int N, int G, int C,
+                              float img_h, float img_w, float neg_thr, float pos_thr,
+                              const float *pred_boxes /*[B,N,4]*/, const float *pred_scores /*[B,N,C]*/,
+                              float gamma, float alpha, float huber_delta,
+                              const float *grad_scale /*device [2]*/, float *grad_boxes /*[B,N,4]*/,
+                              float *grad_scores /*[B,N,C]*/, void *stream);
+
 /* metric.py:9-38 focal_loss(y_true, y_pred, gamma, alpha, from_logits=False, reduction='sum') on
  * dense targets (y_true == 1 marks the positive class): out[1] = sum over all n elements
  * (out has room for 4 floats: out[0], out[2], out[3] are written as 0).  grad [n] or NULL:

@@ -413,11 +413,19 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     const float4 *__restrict__ anchors, const float4 *__restrict__ gt_boxes,
     const int32_t *__restrict__ gt_labels, int N, int G, int C, float img_h, float img_w,
     float neg_thr, float pos_thr, const float4 *__restrict__ pred_boxes, const float *__restrict__ pred_scores,
-    LossParams lp, float4 *__restrict__ grad_boxes, float *__restrict__ grad_scores,
-    float *__restrict__ partials, uint32_t tiles_per_image, uint32_t c_magic)
+    LossParams lp, const float *__restrict__ grad_scale, float4 *__restrict__ grad_boxes,
+    float *__restrict__ grad_scores, float *__restrict__ partials, uint32_t tiles_per_image, uint32_t c_magic)
 {
     __shared__ float s_live[ME_TILE];           // 1.0 = anchor counts (state != -1), 0.0 = ignored
     __shared__ float s_red[3][ME_TILE / WAVE];
+
+    // backward entry point: gradients times two device-resident factors (box, score) -- the
+    // 1 / npos normaliser and the upstream gradient folded in, so no second pass over [B,N,C]
+    float gs_box = 1.0f, gs_cls = 1.0f;
+    if (GRADS && grad_scale) {
+        gs_box = grad_scale[0];
+        gs_cls = grad_scale[1];
+    }
 
     const uint32_t tid = threadIdx.x;
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
                 const float ae = fabsf(e[k]);
                 const bool quad = ae <= lp.delta;
                 h += quad ? 0.5f * (e[k] * e[k]) : lp.delta * ae - 0.5f * (lp.delta * lp.delta);
-                ge[k] = (quad ? e[k] : (e[k] > 0.0f ? lp.delta : -lp.delta)) * 0.25f;
+                ge[k] = ((quad ? e[k] : (e[k] > 0.0f ? lp.delta : -lp.delta)) * 0.25f) * gs_box;
             }
             dist = h * 0.25f;                                             // K.mean over the 4 coordinates
             npos = 1.0f;
@@ -487,7 +495,7 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
             const float m = s_live[q];
             float g = 0.0f;
             cls += m * focal_neg<G15, GRADS>(p[e], lp, cneg, g);
-            if (GRADS) gp[e] = m * g;
+            if (GRADS) gp[e] = g * (m * gs_cls);            // m is exactly 0 or 1
         };
         if (tid < head) one(tid);
         if (d >= 4) {
@@ -504,7 +512,7 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
                 if (ALIGNED) {
                     cls += m0 * ((l[0] + l[1]) + (l[2] + l[3]));
 #pragma unroll
-                    for (uint32_t k = 0; k < 4; ++k) g[k] *= m0;
+                    for (uint32_t k = 0; k < 4; ++k) g[k] *= m0 * gs_cls;
                 } else {
                     // a 16-byte vector spans at most two anchors: q (elements k < left) and q + 1
                     const float m1 = s_live[min(q + 1, (uint32_t)ME_TILE - 1)];
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
                     for (uint32_t k = 0; k < 4; ++k) {
                         const float m = k < left ? m0 : m1;
                         cls += m * l[k];
-                        g[k] *= m;
+                        g[k] *= m * gs_cls;
                     }
                 }
                 if (GRADS) {
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
         if (has_pos) cls += lpos - lneg;
         if (GRADS) {
             __syncthreads();                     // the streaming stores of this tile are done
-            if (has_pos) gp[pos_e] = g1;
+            if (has_pos) gp[pos_e] = g1 * gs_cls;
         }
     }
 
@@ -555,7 +563,7 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
         if ((tid & 63u) == 0) s_red[k][tid >> 6] = x;
     }
     __syncthreads();
-    if (tid < 3) {
+    if (tid < 3 && partials) {
         float x = 0.0f;
         for (int w = 0; w < ME_TILE / WAVE; ++w) x += s_red[tid][w];
         partials[(size_t)blk * 3 + tid] = x;
@@ -760,38 +768,44 @@ size_t odbox_match_loss_workspace(int B, int N)
     return (tiles * (size_t)B * 3 * sizeof(float) + 255) / 256 * 256;
 }
 
-int odbox_match_loss(const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B, int N, int G,
-                     int C, float img_h, float img_w, float neg_thr, float pos_thr, const float *pred_boxes,
-                     const float *pred_scores, float gamma, float alpha, float huber_delta, float *out_loss,
-                     float *grad_boxes, float *grad_scores, void *workspace, size_t workspace_bytes, void *stream)
+// Shared by odbox_match_loss (out_loss + optional unscaled gradients) and odbox_match_loss_backward
+// (gradients only, times grad_scale[2] read on the device).
+static int match_loss_run(const char *name, const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B,
+                          int N, int G, int C, float img_h, float img_w, float neg_thr, float pos_thr,
+                          const float *pred_boxes, const float *pred_scores, float gamma, float alpha, float huber_delta,
+                          float *out_loss, const float *grad_scale, float *grad_boxes, float *grad_scores,
+                          void *workspace, size_t workspace_bytes, void *stream)
 {
     if (B < 1 || N < 1 || G < 1 || C < 1 || C > ODBOX_MAX_CLASSES)
-        return fail(ODBOX_EINVAL, "odbox_match_loss: bad shape B=%d N=%d G=%d C=%d (need B,N,G>=1, 1<=C<=%d)", B, N, G, C,
+        return fail(ODBOX_EINVAL, "%s: bad shape B=%d N=%d G=%d C=%d (need B,N,G>=1, 1<=C<=%d)", name, B, N, G, C,
                     ODBOX_MAX_CLASSES);
-    if (!anchors || !gt_boxes || !gt_labels || !pred_boxes || !pred_scores || !out_loss)
-        return fail(ODBOX_EINVAL, "odbox_match_loss: NULL pointer");
+    if (!anchors || !gt_boxes || !gt_labels || !pred_boxes || !pred_scores) return fail(ODBOX_EINVAL, "%s: NULL pointer", name);
     if ((grad_boxes == nullptr) != (grad_scores == nullptr))
-        return fail(ODBOX_EINVAL, "odbox_match_loss: pass both gradient buffers or neither");
+        return fail(ODBOX_EINVAL, "%s: pass both gradient buffers or neither", name);
     if (!aligned16(anchors) || !aligned16(gt_boxes) || !aligned16(pred_boxes) || (grad_boxes && !aligned16(grad_boxes)))
-        return fail(ODBOX_EINVAL, "odbox_match_loss: box tensors must be 16-byte aligned");
+        return fail(ODBOX_EINVAL, "%s: box tensors must be 16-byte aligned", name);
     if (((uintptr_t)pred_scores & 3u) || (grad_scores && ((uintptr_t)pred_scores & 15u) != ((uintptr_t)grad_scores & 15u)))
-        return fail(ODBOX_EINVAL, "odbox_match_loss: grad_scores must have the 16-byte phase of pred_scores");
-    const size_t need = odbox_match_loss_workspace(B, N);
-    if (!workspace || workspace_bytes < need)
-        return fail(ODBOX_ENOSPC, "odbox_match_loss: workspace %zu bytes, need %zu", workspace_bytes, need);
+        return fail(ODBOX_EINVAL, "%s: grad_scores must have the 16-byte phase of pred_scores", name);
+    if (grad_scale && ((uintptr_t)grad_scale & 3u)) return fail(ODBOX_EINVAL, "%s: grad_scale must be 4-byte aligned", name);
+    if (out_loss) {
+        const size_t need = odbox_match_loss_workspace(B, N);
+        if (!workspace || workspace_bytes < need)
+            return fail(ODBOX_ENOSPC, "%s: workspace %zu bytes, need %zu", name, workspace_bytes, need);
+    }
     const uint64_t tiles = ((uint64_t)N + ME_TILE - 1) / ME_TILE;
     const uint64_t blocks = tiles * (uint64_t)B;
-    if (blocks > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_match_loss: grid too large");
+    if (blocks > 0x7fffffffull) return fail(ODBOX_EINVAL, "%s: grid too large", name);
     const uint32_t d = (uint32_t)C;
     const uint32_t magic = d == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / d);
     const LossParams lp = {gamma, alpha, huber_delta};
     hipStream_t st = (hipStream_t)stream;
     const bool g15 = gamma == 1.5f;                 // the reference's default: pow as x * sqrt(x)
     const bool al = (d & 3u) == 0 && aligned16(pred_scores);
+    float *partials = out_loss ? (float *)workspace : nullptr;
     auto launch = [&](auto kernel, float4 *gb, float *gs) {
         hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(ME_TILE), 0, st, (const float4 *)anchors,
                            (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w, neg_thr, pos_thr,
-                           (const float4 *)pred_boxes, pred_scores, lp, gb, gs, (float *)workspace, (uint32_t)tiles,
+                           (const float4 *)pred_boxes, pred_scores, lp, grad_scale, gb, gs, partials, (uint32_t)tiles,
                            magic);
     };
     auto pick = [&](auto grads, float4 *gb, float *gs) {
@@ -802,8 +816,31 @@ int odbox_match_loss(const float *anchors, const float *gt_boxes, const int32_t 
     if (grad_scores) pick(std::true_type{}, (float4 *)grad_boxes, grad_scores);
     else pick(std::false_type{}, (float4 *)nullptr, (float *)nullptr);
     if (int rc = launch_status("match_loss")) return rc;
+    if (!out_loss) return 0;
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, st, (const float *)workspace, (uint32_t)blocks, out_loss);
     return launch_status("loss_reduce");
+}
+
+int odbox_match_loss(const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B, int N, int G,
+                     int C, float img_h, float img_w, float neg_thr, float pos_thr, const float *pred_boxes,
+                     const float *pred_scores, float gamma, float alpha, float huber_delta, float *out_loss,
+                     float *grad_boxes, float *grad_scores, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!out_loss) return fail(ODBOX_EINVAL, "odbox_match_loss: NULL pointer");
+    return match_loss_run("odbox_match_loss", anchors, gt_boxes, gt_labels, B, N, G, C, img_h, img_w, neg_thr, pos_thr,
+                          pred_boxes, pred_scores, gamma, alpha, huber_delta, out_loss, nullptr, grad_boxes, grad_scores,
+                          workspace, workspace_bytes, stream);
+}
+
+int odbox_match_loss_backward(const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B, int N, int G,
+                              int C, float img_h, float img_w, float neg_thr, float pos_thr, const float *pred_boxes,
+                              const float *pred_scores, float gamma, float alpha, float huber_delta,
+                              const float *grad_scale, float *grad_boxes, float *grad_scores, void *stream)
+{
+    if (!grad_scale || !grad_boxes || !grad_scores) return fail(ODBOX_EINVAL, "odbox_match_loss_backward: NULL pointer");
+    return match_loss_run("odbox_match_loss_backward", anchors, gt_boxes, gt_labels, B, N, G, C, img_h, img_w, neg_thr,
+                          pos_thr, pred_boxes, pred_scores, gamma, alpha, huber_delta, nullptr, grad_scale, grad_boxes,
+                          grad_scores, nullptr, 0, stream);
 }
 
 size_t odbox_focal_loss_workspace(size_t n)

@@ -24,36 +24,106 @@ def _workspace(dev, need):
     return ws
 
 
+def _focal_launch(lib, y_true, y_pred, gamma, alpha, want_grad):
+    n = y_pred.numel()
+    out = torch.empty(4, dtype=torch.float32, device=y_pred.device)
+    grad = torch.empty_like(y_pred) if want_grad else None
+    ws = _workspace(y_pred.device, lib.odbox_focal_loss_workspace(n))
+    _lib.check(lib.odbox_focal_loss(_lib.ptr(y_true), _lib.ptr(y_pred), n, float(gamma), float(alpha),
+                                    _lib.ptr(out), _lib.ptr(grad), _lib.ptr(ws), ws.numel(),
+                                    _lib.stream_ptr()), 'odbox_focal_loss')
+    return out[1], grad
+
+
+class _FocalLossFn(torch.autograd.Function):
+    """Differentiable dense focal loss (the whole-image head is [B, num_image_classes]: small, so
+    the forward launch writes the gradient and backward only scales it)."""
+
+    @staticmethod
+    def forward(ctx, y_pred, y_true, gamma, alpha):
+        loss, grad = _focal_launch(_lib.load(), y_true, y_pred, gamma, alpha, True)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None
+
+
 def focal_loss(y_true, y_pred, gamma: float = 1.5, alpha: float = 0.25, from_logits: bool = False,
                reduction: str = 'sum', return_grad: bool = False):
     """metric.py:9-38 on dense targets.  reduction 'sum' (default, the only one the reference
-    uses) or 'mean' (mean of the per-row sums).  return_grad=True also returns d loss / d y_pred."""
+    uses) or 'mean' (mean of the per-row sums).  Differentiable w.r.t. y_pred when it requires
+    grad; return_grad=True instead returns d loss / d y_pred explicitly."""
     if from_logits:
         raise NotImplementedError('the reference never calls focal_loss with from_logits=True')
     if reduction not in ('sum', 'mean'):
         raise NotImplementedError("reduction must be 'sum' or 'mean'")
     lib = _lib.load()
     dev = _lib.require_gpu()
-    y_true = _lib.as_dev(y_true, torch.float32, dev)
+    y_true = _lib.as_dev(y_true, torch.float32, dev).detach()
     y_pred = _lib.as_dev(y_pred, torch.float32, dev)
     if y_true.shape != y_pred.shape:
         raise ValueError('y_true %r and y_pred %r differ in shape' % (tuple(y_true.shape), tuple(y_pred.shape)))
     n = y_pred.numel()
-    out = torch.empty(4, dtype=torch.float32, device=dev)
-    grad = torch.empty_like(y_pred) if return_grad else None
-    ws = _workspace(dev, lib.odbox_focal_loss_workspace(n))
-    _lib.check(lib.odbox_focal_loss(_lib.ptr(y_true), _lib.ptr(y_pred), n, float(gamma), float(alpha),
-                                    _lib.ptr(out), _lib.ptr(grad), _lib.ptr(ws), ws.numel(),
-                                    _lib.stream_ptr()), 'odbox_focal_loss')
-    loss = out[1]
     scale = 1.0
     if reduction == 'mean':
         rows = max(1, n // max(1, y_pred.shape[-1])) if y_pred.dim() else 1
         scale = 1.0 / rows
+    if not return_grad and torch.is_grad_enabled() and y_pred.requires_grad:
+        loss = _FocalLossFn.apply(y_pred, y_true, gamma, alpha)
+        return loss * scale if scale != 1.0 else loss
+    loss, grad = _focal_launch(lib, y_true, y_pred.detach(), gamma, alpha, return_grad)
+    if scale != 1.0:
         loss = loss * scale
     if return_grad:
         return loss, (grad * scale if scale != 1.0 else grad)
     return loss
+
+
+def _loss_args(lib, anchors, image_hw, gt, lab, B, N, G, C, neg, pos, pb, ps):
+    return (_lib.ptr(anchors), _lib.ptr(gt), _lib.ptr(lab), B, N, G, C, float(image_hw[0]), float(image_hw[1]),
+            float(neg), float(pos), _lib.ptr(pb), _lib.ptr(ps))
+
+
+class _DetectionLossFn(torch.autograd.Function):
+    """(pred_bboxes, pred_scores) -> (dist_loss, class_loss, npos) with a HIP backward: the forward
+    launch computes no gradients; the backward launch (`odbox_match_loss_backward`) re-matches and
+    writes both gradients once, already multiplied by upstream_gradient / npos read on the device."""
+
+    @staticmethod
+    def forward(ctx, pb, ps, anchors, gt, lab, image_hw, cfg):
+        lib = _lib.load()
+        B, N, G, C, neg, pos, gamma, alpha, delta = cfg
+        out = torch.empty(4, dtype=torch.float32, device=pb.device)
+        ws = _workspace(pb.device, lib.odbox_match_loss_workspace(B, N))
+        _lib.check(lib.odbox_match_loss(
+            *_loss_args(lib, anchors, image_hw, gt, lab, B, N, G, C, neg, pos, pb, ps),
+            float(gamma), float(alpha), float(delta), _lib.ptr(out), None, None, _lib.ptr(ws), ws.numel(),
+            _lib.stream_ptr()), 'odbox_match_loss')
+        ctx.save_for_backward(pb, ps, anchors, gt, lab, out)
+        ctx.image_hw, ctx.cfg = image_hw, cfg
+        dist, cls, npos = out[0], out[1], out[2]
+        ctx.mark_non_differentiable(npos)
+        return dist, cls, npos
+
+    @staticmethod
+    def backward(ctx, g_dist, g_cls, _g_npos):
+        lib = _lib.load()
+        pb, ps, anchors, gt, lab, out = ctx.saved_tensors
+        B, N, G, C, neg, pos, gamma, alpha, delta = ctx.cfg
+        zero = out.new_zeros(())
+        up = torch.stack([zero if g_dist is None else g_dist.to(torch.float32),
+                          zero if g_cls is None else g_cls.to(torch.float32)])
+        scale = (up / torch.where(out[2] != 0, out[2], torch.ones_like(out[2]))).contiguous()
+        gb = torch.empty_like(pb)
+        gs = torch.empty_like(ps)
+        _lib.check(lib.odbox_match_loss_backward(
+            *_loss_args(lib, anchors, ctx.image_hw, gt, lab, B, N, G, C, neg, pos, pb, ps),
+            float(gamma), float(alpha), float(delta), _lib.ptr(scale), _lib.ptr(gb), _lib.ptr(gs),
+            _lib.stream_ptr()), 'odbox_match_loss_backward')
+        return gb, gs, None, None, None, None, None
 
 
 def detection_loss(anchors, image_hw, true_bboxes, true_labels, pred_bboxes, pred_scores, num_classes,
@@ -61,8 +131,12 @@ def detection_loss(anchors, image_hw, true_bboxes, true_labels, pred_bboxes, pre
                    return_grads=False):
     """The fused matcher + loss (`odbox_match_loss`).  Returns (dist_loss, class_loss, normalizer)
     as device scalars, both losses divided by normalizer = #foreground anchors when it is not 0
-    (metric.py:108-123).  return_grads=True adds (grad_boxes [B,N,4], grad_scores [B,N,C]): the
-    gradients of the two RETURNED losses w.r.t. pred_bboxes / pred_scores."""
+    (metric.py:108-123).
+
+    When pred_bboxes / pred_scores require grad (and grad mode is on) the two losses are
+    differentiable: `.backward()` runs `odbox_match_loss_backward`.  return_grads=True instead
+    returns (grad_boxes [B,N,4], grad_scores [B,N,C]) explicitly, in one launch with the losses:
+    the gradients of the two RETURNED losses w.r.t. pred_bboxes / pred_scores."""
     lib = _lib.load()
     dev = _lib.require_gpu()
     anchors = _lib.as_dev(anchors, torch.float32, dev)
@@ -75,6 +149,10 @@ def detection_loss(anchors, image_hw, true_bboxes, true_labels, pred_bboxes, pre
     if tuple(lab.shape) != (B, G) or tuple(pb.shape) != (B, N, 4) or tuple(ps.shape) != (B, N, C):
         raise ValueError('shape mismatch: labels %r, pred_bboxes %r, pred_scores %r for B=%d N=%d G=%d C=%d'
                          % (tuple(lab.shape), tuple(pb.shape), tuple(ps.shape), B, N, G, C))
+    if not return_grads and torch.is_grad_enabled() and (pb.requires_grad or ps.requires_grad):
+        cfg = (B, N, G, C, negative_overlap, positive_overlap, gamma, alpha, huber_delta)
+        return _DetectionLossFn.apply(pb, ps, anchors.detach(), gt.detach(), lab, (float(image_hw[0]), float(image_hw[1])), cfg)
+    pb, ps = pb.detach(), ps.detach()
     out = torch.empty(4, dtype=torch.float32, device=dev)
     gb = gs = None
     if return_grads:
@@ -82,14 +160,13 @@ def detection_loss(anchors, image_hw, true_bboxes, true_labels, pred_bboxes, pre
         gs = torch.empty_like(ps)
     ws = _workspace(dev, lib.odbox_match_loss_workspace(B, N))
     _lib.check(lib.odbox_match_loss(
-        _lib.ptr(anchors), _lib.ptr(gt), _lib.ptr(lab), B, N, G, C, float(image_hw[0]), float(image_hw[1]),
-        float(negative_overlap), float(positive_overlap), _lib.ptr(pb), _lib.ptr(ps),
+        *_loss_args(lib, anchors, image_hw, gt, lab, B, N, G, C, negative_overlap, positive_overlap, pb, ps),
         float(gamma), float(alpha), float(huber_delta), _lib.ptr(out), _lib.ptr(gb), _lib.ptr(gs),
         _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), 'odbox_match_loss')
     if return_grads:
         # the kernel returns gradients of the unnormalised sums; scale on the device, no sync
         inv = torch.where(out[2] != 0, 1.0 / out[2], torch.ones_like(out[2]))
-        return out[0], out[1], out[2], gb * inv, gs * inv
+        return out[0], out[1], out[2], gb.mul_(inv), gs.mul_(inv)
     return out[0], out[1], out[2]
 
 

@@ -130,3 +130,60 @@ def test_cfg2_full_batch_losses_and_gradients():
     assert lin_d > 0 and lin_c > 0
     np.testing.assert_allclose((float(d1) - float(d2)) / (2 * h), lin_d, rtol=0.02)
     np.testing.assert_allclose((float(c1) - float(c2)) / (2 * h), lin_c, rtol=0.02)
+
+
+@pytest.mark.parametrize('C,offset', [(5, 0), (80, 0), (7, 1)])
+def test_autograd_backward_entry_point(C, offset):
+    """`.backward()` through the losses (odbox_match_loss_backward: gradients times upstream / npos
+    read on the device) against the oracle's analytic gradients, with unequal loss weights, an
+    aligned and an unaligned class count, and a score tensor that starts off a 16-byte boundary."""
+    anchors, hw, gt, lab, pb, ps, C = _case(21 + C, B=2, C=C)
+    dev = torch.device('cuda')
+    tpb = torch.as_tensor(pb, device=dev).requires_grad_(True)
+    flat = torch.zeros(ps.size + 4, device=dev)
+    tps = flat[offset:offset + ps.size].view(ps.shape)
+    tps.data.copy_(torch.as_tensor(ps))
+    tps = tps.detach().requires_grad_(True)
+    d, c, n = M.detection_loss(anchors, hw, gt, lab, tpb, tps, C)
+    assert d.requires_grad and c.requires_grad and not n.requires_grad
+    (2.0 * d + 0.5 * c).backward()
+    rd, rc, rn, rgb, rgs = O.model_metric(anchors, hw, gt, lab, pb, ps, C, with_grads=True)
+    np.testing.assert_allclose([float(d.detach()), float(c.detach())], [rd, rc], rtol=RTOL)
+    eb, es = 2.0 * rgb / rn, 0.5 * rgs / rn
+    np.testing.assert_allclose(tpb.grad.cpu().numpy(), eb, rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(tps.grad.cpu().numpy(), es, rtol=1e-4, atol=1e-6 * np.abs(es).max())
+    # the explicit-gradient launch and the backward launch agree to the last bit up to the scale's rounding
+    _, _, _, gb, gs = M.detection_loss(anchors, hw, gt, lab, pb, ps, C, return_grads=True)
+    np.testing.assert_allclose(tpb.grad.cpu().numpy(), 2.0 * gb.cpu().numpy(), rtol=1e-6, atol=0)
+    np.testing.assert_allclose(tps.grad.cpu().numpy(), 0.5 * gs.cpu().numpy(), rtol=1e-6, atol=0)
+    # only one of the two losses used: the other branch gets exact zeros, nothing is left unwritten
+    tpb.grad = None
+    tps.grad = None
+    d, c, n = M.detection_loss(anchors, hw, gt, lab, tpb, tps, C)
+    c.backward()
+    assert (tpb.grad == 0).all()
+    np.testing.assert_allclose(tps.grad.cpu().numpy(), gs.cpu().numpy(), rtol=1e-6, atol=0)
+
+
+def test_autograd_model_metric_and_image_head():
+    rng = np.random.default_rng(5)
+    anchors, hw, gt, lab, pb, ps, C = _case(31, B=2, C=3)
+    y = (rng.uniform(size=(2, 9)) < 0.3).astype(F)
+    p = rng.uniform(0.05, 0.95, (2, 9)).astype(F)
+    dev = torch.device('cuda')
+    tpb = torch.as_tensor(pb, device=dev).requires_grad_(True)
+    tps = torch.as_tensor(ps, device=dev).requires_grad_(True)
+    tp = torch.as_tensor(p, device=dev).requires_grad_(True)
+    mm = M.ModelMetric(anchors, C)
+    images = np.zeros((2, hw[0], hw[1], 3), F)
+    d, c, i = mm(images, gt, lab, y, tpb, tps, tp, True)
+    (d + c + 3.0 * i).backward()
+    _, _, _, gb, gs = M.detection_loss(anchors, hw, gt, lab, pb, ps, C, return_grads=True)
+    _, gi = M.focal_loss(y, p, return_grad=True)
+    np.testing.assert_allclose(tpb.grad.cpu().numpy(), gb.cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(tps.grad.cpu().numpy(), gs.cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(tp.grad.cpu().numpy(), 3.0 * gi.cpu().numpy(), rtol=1e-6)
+    # under no_grad nothing is recorded
+    with torch.no_grad():
+        d, c, i = mm(images, gt, lab, y, tpb, tps, tp, False)
+    assert not d.requires_grad and not i.requires_grad

@@ -107,6 +107,18 @@ def main():
             byts = B * (N * (32 + 4 * C) + 20 * G) * (1 if g1 is None else 2)
             rows.append(dict(cfg=name, B=B, N=N, G=G, C=C, us=t * 1e6, img_s=B / t, GBs=byts / t / 1e9,
                              frac_hbm=byts / t / 1e9 / HBM))
+        # the autograd backward launch: gradients only, times two device-resident factors
+        scale = torch.tensor([0.5, 0.25], device=dev)
+
+        def step_bwd():
+            rc = lib.odbox_match_loss_backward(anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C, float(c['S']),
+                                               float(c['S']), 0.4, 0.5, pb.data_ptr(), ps.data_ptr(), 1.5, 0.25, 1.0,
+                                               scale.data_ptr(), gb.data_ptr(), gs.data_ptr(), st)
+            assert rc == 0
+        t = event_time(step_bwd, args.iters)
+        byts = B * (N * (32 + 4 * C) + 20 * G) * 2
+        rows.append(dict(cfg='2_loss_backward', B=B, N=N, G=G, C=C, us=t * 1e6, img_s=B / t, GBs=byts / t / 1e9,
+                         frac_hbm=byts / t / 1e9 / HBM))
     # COCO matching of the gathered detections of one cfg-5 eval batch (512 images)
     if 6 in args.cfg:
         import ctypes
