@@ -94,6 +94,27 @@ int odbox_match_loss_backward(const float *anchors /*[N,4]*/, const float *gt_bo
                               const float *grad_scale /*device [2]*/, float *grad_boxes /*[B,N,4]*/,
                               float *grad_scores /*[B,N,C]*/, void *stream);
 
+/* The same two entry points for fp16 predictions: the reference's --use_fp16 run (detection.py:
+ * 296-300, mixed_float16) hands fp16 model outputs to metric.py, which casts them to fp32 before
+ * any arithmetic (metric.py:16-17; Keras' Huber does the same).  Here the four prediction /
+ * gradient tensors are IEEE binary16 in memory: widened on load (exact), all arithmetic in fp32,
+ * gradients rounded to nearest even on store; out_loss and grad_scale stay fp32.  Half the bytes
+ * of the dominant stream.  pred_boxes / grad_boxes 8-byte aligned, scores 2-byte aligned with
+ * grad_scores on the 16-byte phase of pred_scores. */
+int odbox_match_loss_f16(const float *anchors, const float *gt_boxes, const int32_t *gt_labels,
+                         int B, int N, int G, int C, float img_h, float img_w, float neg_thr,
+                         float pos_thr, const void *pred_boxes /*f16 [B,N,4]*/,
+                         const void *pred_scores /*f16 [B,N,C]*/, float gamma, float alpha,
+                         float huber_delta, float *out_loss /*[4]*/, void *grad_boxes /*f16 or NULL*/,
+                         void *grad_scores /*f16 or NULL*/, void *workspace, size_t workspace_bytes,
+                         void *stream);
+int odbox_match_loss_backward_f16(const float *anchors, const float *gt_boxes, const int32_t *gt_labels,
+                                  int B, int N, int G, int C, float img_h, float img_w, float neg_thr,
+                                  float pos_thr, const void *pred_boxes, const void *pred_scores,
+                                  float gamma, float alpha, float huber_delta,
+                                  const float *grad_scale /*device [2], fp32*/, void *grad_boxes,
+                                  void *grad_scores, void *stream);
+
 /* metric.py:9-38 focal_loss(y_true, y_pred, gamma, alpha, from_logits=False, reduction='sum') on
  * dense targets (y_true == 1 marks the positive class): out[1] = sum over all n elements
  * (out has room for 4 floats: out[0], out[2], out[3] are written as 0).  grad [n] or NULL:

@@ -408,14 +408,64 @@ __device__ __forceinline__ float focal_neg(float pred, const LossParams lp, floa
     return (cneg * w) * l2;
 }
 
-template <bool GRADS, bool G15, bool ALIGNED>
+// Element type of the predictions and of their gradients: float, or _Float16 for the reference's
+// --use_fp16 (mixed_float16) training, where metric.py:16-17 and Keras' Huber cast the fp16 model
+// outputs to fp32 before any arithmetic.  Same here: widen on load (exact), fp32 arithmetic,
+// gradients rounded to nearest even on store.  A 16-byte vector holds VEC elements.
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+
+template <typename T> struct PredIO;
+template <> struct PredIO<float> {
+    static constexpr uint32_t VEC = 4;
+    typedef v4f vec_t;
+    typedef float4 box_t;
+    static __device__ __forceinline__ vec_t fill(float x) { return vec_t{x, x, x, x}; }
+    static __device__ __forceinline__ void unpack(vec_t v, float (&x)[4]) { x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
+    static __device__ __forceinline__ vec_t pack(const float (&g)[4]) { return vec_t{g[0], g[1], g[2], g[3]}; }
+    static __device__ __forceinline__ float4 load_box(const box_t *p, size_t row) { return p[row]; }
+    static __device__ __forceinline__ void store_box(box_t *p, size_t row, float4 v) { p[row] = v; }
+};
+template <> struct PredIO<_Float16> {
+    static constexpr uint32_t VEC = 8;
+    typedef v8h vec_t;
+    typedef v4h box_t;
+    static __device__ __forceinline__ vec_t fill(float x) { const _Float16 h = (_Float16)x; return vec_t{h, h, h, h, h, h, h, h}; }
+    static __device__ __forceinline__ void unpack(vec_t v, float (&x)[8])
+    {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = (float)v[k];
+    }
+    static __device__ __forceinline__ vec_t pack(const float (&g)[8])
+    {
+        vec_t v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (_Float16)g[k];
+        return v;
+    }
+    static __device__ __forceinline__ float4 load_box(const box_t *p, size_t row)
+    {
+        const v4h v = p[row];
+        return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    }
+    static __device__ __forceinline__ void store_box(box_t *p, size_t row, float4 v)
+    {
+        p[row] = v4h{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    }
+};
+
+template <typename T, bool GRADS, bool G15, bool ALIGNED>
 __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     const float4 *__restrict__ anchors, const float4 *__restrict__ gt_boxes,
     const int32_t *__restrict__ gt_labels, int N, int G, int C, float img_h, float img_w,
-    float neg_thr, float pos_thr, const float4 *__restrict__ pred_boxes, const float *__restrict__ pred_scores,
-    LossParams lp, const float *__restrict__ grad_scale, float4 *__restrict__ grad_boxes,
-    float *__restrict__ grad_scores, float *__restrict__ partials, uint32_t tiles_per_image, uint32_t c_magic)
+    float neg_thr, float pos_thr, const typename PredIO<T>::box_t *__restrict__ pred_boxes,
+    const T *__restrict__ pred_scores, LossParams lp, const float *__restrict__ grad_scale,
+    typename PredIO<T>::box_t *__restrict__ grad_boxes, T *__restrict__ grad_scores, float *__restrict__ partials,
+    uint32_t tiles_per_image, uint32_t c_magic)
 {
+    using IO = PredIO<T>;
+    constexpr uint32_t VEC = IO::VEC;
+    typedef typename IO::vec_t vec_t;
     __shared__ float s_live[ME_TILE];           // 1.0 = anchor counts (state != -1), 0.0 = ignored
     __shared__ float s_red[3][ME_TILE / WAVE];
 
@@ -434,18 +484,18 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     const uint32_t tile_n = min((uint32_t)ME_TILE, (uint32_t)N - n0);
 
     // The tile's [tile_n, C] predictions are one contiguous run: 16-byte loads over the flat element
-    // range (scalar head / tail for the 4-byte-aligned ends; ALIGNED = C % 4 == 0 and a 16-byte
+    // range (scalar head / tail for the element-aligned ends; ALIGNED = C % VEC == 0 and a 16-byte
     // aligned tensor: no head, and a vector never straddles two anchors).  The first load is issued
     // before the match so its latency hides behind the GT loop.
     const uint32_t d = (uint32_t)C;
     const size_t soff = ((size_t)b * N + n0) * d;
-    const float *p = pred_scores + soff;
+    const T *p = pred_scores + soff;
     const uint32_t count = tile_n * d;
-    const uint32_t head = ALIGNED ? 0u : min(count, (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) >> 2);
-    const uint32_t nvec = (count - head) >> 2;
-    const v4f *pv4 = reinterpret_cast<const v4f *>(p + head);
-    v4f cur = {0.5f, 0.5f, 0.5f, 0.5f};
-    if (d >= 4 && nvec) cur = pv4[min(tid, nvec - 1)];
+    const uint32_t head = ALIGNED ? 0u : min(count, (uint32_t)(((16u - ((uintptr_t)p & 15u)) & 15u) / sizeof(T)));
+    const uint32_t nvec = (count - head) / VEC;
+    const vec_t *pv4 = reinterpret_cast<const vec_t *>(p + head);
+    vec_t cur = IO::fill(0.5f);
+    if (d >= VEC && nvec) cur = pv4[min(tid, nvec - 1)];
 
     const TileMatch tm = match_tile<ME_TILE>(anchors, gt_boxes, gt_labels, b, n0, N, G, C, img_h, img_w, neg_thr, pos_thr);
     s_live[tid] = tm.live && tm.state != -1 ? 1.0f : 0.0f;
@@ -453,7 +503,7 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     // the one y = 1 element of a foreground anchor: fetch it now, correct the sum after the stream
     const bool has_pos = tm.live && tm.state == 1 && tm.label >= 0;
     const uint32_t pos_e = tid * d + (uint32_t)max(tm.label, 0);
-    const float pos_x = has_pos ? p[pos_e] : 0.5f;
+    const float pos_x = has_pos ? (float)p[pos_e] : 0.5f;
 
     // ---- box loss: Huber over the 4 offsets of every foreground anchor ------------------------
     float dist = 0.0f, npos = 0.0f;
@@ -466,7 +516,7 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
             const float aw = a.z - a.x, ah = a.w - a.y;
             const float t[4] = {(((g.x - a.x) / aw) - 0.0f) / 0.2f, (((g.y - a.y) / ah) - 0.0f) / 0.2f,
                                 (((g.z - a.z) / aw) - 0.0f) / 0.2f, (((g.w - a.w) / ah) - 0.0f) / 0.2f};   // anchors.py:286-297
-            const float4 pb = pred_boxes[row];
+            const float4 pb = IO::load_box(pred_boxes, row);
             const float e[4] = {pb.x - t[0], pb.y - t[1], pb.z - t[2], pb.w - t[3]};
             float h = 0.0f, ge[4];
 #pragma unroll
@@ -480,45 +530,50 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
             npos = 1.0f;
             gbox = make_float4(ge[0], ge[1], ge[2], ge[3]);
         }
-        if (GRADS && grad_boxes) grad_boxes[row] = gbox;
+        if (GRADS && grad_boxes) IO::store_box(grad_boxes, row, gbox);
     }
     __syncthreads();
 
     // ---- class loss: every element as y = 0, masked by its anchor's live flag ------------------
     const float cneg = -(1.0f - lp.alpha) * 0.69314718f;
     float cls = 0.0f;
-    float *gp = GRADS ? grad_scores + soff : nullptr;
+    T *gp = GRADS ? grad_scores + soff : nullptr;
     {
         auto one = [&](uint32_t e) {
             uint32_t q, r;
             divmod_u32(e, d, c_magic, q, r);
             const float m = s_live[q];
             float g = 0.0f;
-            cls += m * focal_neg<G15, GRADS>(p[e], lp, cneg, g);
-            if (GRADS) gp[e] = g * (m * gs_cls);            // m is exactly 0 or 1
+            cls += m * focal_neg<G15, GRADS>((float)p[e], lp, cneg, g);
+            if (GRADS) gp[e] = (T)(g * (m * gs_cls));       // m is exactly 0 or 1
         };
         if (tid < head) one(tid);
-        if (d >= 4) {
+        if (d >= VEC) {
             for (uint32_t v = tid; v < nvec; v += ME_TILE) {
-                const v4f nxt = pv4[min(v + ME_TILE, nvec - 1)];   // prefetch, clamped => unconditional
-                const uint32_t e = head + 4 * v;
+                const vec_t nxt = pv4[min(v + ME_TILE, nvec - 1)];   // prefetch, clamped => unconditional
+                const uint32_t e = head + VEC * v;
                 uint32_t q, r;
                 divmod_u32(e, d, c_magic, q, r);
                 const float m0 = s_live[q];
-                const float in[4] = {cur.x, cur.y, cur.z, cur.w};
-                float g[4] = {0.f, 0.f, 0.f, 0.f}, l[4];
+                float in[VEC], g[VEC], l[VEC];
+                IO::unpack(cur, in);
 #pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) l[k] = focal_neg<G15, GRADS>(in[k], lp, cneg, g[k]);
+                for (uint32_t k = 0; k < VEC; ++k) {
+                    g[k] = 0.0f;
+                    l[k] = focal_neg<G15, GRADS>(in[k], lp, cneg, g[k]);
+                }
                 if (ALIGNED) {
-                    cls += m0 * ((l[0] + l[1]) + (l[2] + l[3]));
+                    float s4 = (l[0] + l[1]) + (l[2] + l[3]);
+                    if (VEC == 8) s4 += (l[VEC - 4] + l[VEC - 3]) + (l[VEC - 2] + l[VEC - 1]);
+                    cls += m0 * s4;
 #pragma unroll
-                    for (uint32_t k = 0; k < 4; ++k) g[k] *= m0 * gs_cls;
+                    for (uint32_t k = 0; k < VEC; ++k) g[k] *= m0 * gs_cls;
                 } else {
-                    // a 16-byte vector spans at most two anchors: q (elements k < left) and q + 1
+                    // a 16-byte vector spans at most two anchors (d >= VEC): q (elements k < left) and q + 1
                     const float m1 = s_live[min(q + 1, (uint32_t)ME_TILE - 1)];
                     const uint32_t left = d - r;
 #pragma unroll
-                    for (uint32_t k = 0; k < 4; ++k) {
+                    for (uint32_t k = 0; k < VEC; ++k) {
                         const float m = k < left ? m0 : m1;
                         cls += m * l[k];
                         g[k] *= m * gs_cls;
@@ -529,15 +584,14 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
                     // A compiler-visible store on purpose: the matched-class fix-up below overwrites one of
                     // these elements after the barrier, and only stores the compiler knows about are
                     // waited for (s_waitcnt) in front of it -- an inline-asm store raced with the fix-up.
-                    const v4f gv = {g[0], g[1], g[2], g[3]};
-                    __builtin_nontemporal_store(gv, reinterpret_cast<v4f *>(gp + e));
+                    __builtin_nontemporal_store(IO::pack(g), reinterpret_cast<vec_t *>(gp + e));
                 }
                 cur = nxt;
             }
         } else {
-            for (uint32_t e = head + tid; e < head + 4 * nvec; e += ME_TILE) one(e);
+            for (uint32_t e = head + tid; e < head + VEC * nvec; e += ME_TILE) one(e);
         }
-        const uint32_t done = head + 4 * nvec;
+        const uint32_t done = head + VEC * nvec;
         if (tid < count - done) one(done + tid);
     }
 
@@ -549,7 +603,7 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
         if (has_pos) cls += lpos - lneg;
         if (GRADS) {
             __syncthreads();                     // the streaming stores of this tile are done
-            if (has_pos) gp[pos_e] = g1 * gs_cls;
+            if (has_pos) gp[pos_e] = (T)(g1 * gs_cls);
         }
     }
 
@@ -770,21 +824,27 @@ size_t odbox_match_loss_workspace(int B, int N)
 
 // Shared by odbox_match_loss (out_loss + optional unscaled gradients) and odbox_match_loss_backward
 // (gradients only, times grad_scale[2] read on the device).
+// T = element type of the four prediction / gradient tensors (float or _Float16).
+extern "C++" {
+template <typename T>
 static int match_loss_run(const char *name, const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B,
                           int N, int G, int C, float img_h, float img_w, float neg_thr, float pos_thr,
-                          const float *pred_boxes, const float *pred_scores, float gamma, float alpha, float huber_delta,
-                          float *out_loss, const float *grad_scale, float *grad_boxes, float *grad_scores,
+                          const T *pred_boxes, const T *pred_scores, float gamma, float alpha, float huber_delta,
+                          float *out_loss, const float *grad_scale, T *grad_boxes, T *grad_scores,
                           void *workspace, size_t workspace_bytes, void *stream)
 {
+    typedef typename PredIO<T>::box_t box_t;
+    constexpr uintptr_t box_mask = sizeof(box_t) - 1, el_mask = sizeof(T) - 1;
     if (B < 1 || N < 1 || G < 1 || C < 1 || C > ODBOX_MAX_CLASSES)
         return fail(ODBOX_EINVAL, "%s: bad shape B=%d N=%d G=%d C=%d (need B,N,G>=1, 1<=C<=%d)", name, B, N, G, C,
                     ODBOX_MAX_CLASSES);
     if (!anchors || !gt_boxes || !gt_labels || !pred_boxes || !pred_scores) return fail(ODBOX_EINVAL, "%s: NULL pointer", name);
     if ((grad_boxes == nullptr) != (grad_scores == nullptr))
         return fail(ODBOX_EINVAL, "%s: pass both gradient buffers or neither", name);
-    if (!aligned16(anchors) || !aligned16(gt_boxes) || !aligned16(pred_boxes) || (grad_boxes && !aligned16(grad_boxes)))
-        return fail(ODBOX_EINVAL, "%s: box tensors must be 16-byte aligned", name);
-    if (((uintptr_t)pred_scores & 3u) || (grad_scores && ((uintptr_t)pred_scores & 15u) != ((uintptr_t)grad_scores & 15u)))
+    if (!aligned16(anchors) || !aligned16(gt_boxes) || ((uintptr_t)pred_boxes & box_mask) || ((uintptr_t)grad_boxes & box_mask))
+        return fail(ODBOX_EINVAL, "%s: anchors / gt_boxes must be 16-byte aligned, pred_boxes / grad_boxes %zu-byte", name,
+                    sizeof(box_t));
+    if (((uintptr_t)pred_scores & el_mask) || (grad_scores && ((uintptr_t)pred_scores & 15u) != ((uintptr_t)grad_scores & 15u)))
         return fail(ODBOX_EINVAL, "%s: grad_scores must have the 16-byte phase of pred_scores", name);
     if (grad_scale && ((uintptr_t)grad_scale & 3u)) return fail(ODBOX_EINVAL, "%s: grad_scale must be 4-byte aligned", name);
     if (out_loss) {
@@ -800,26 +860,27 @@ static int match_loss_run(const char *name, const float *anchors, const float *g
     const LossParams lp = {gamma, alpha, huber_delta};
     hipStream_t st = (hipStream_t)stream;
     const bool g15 = gamma == 1.5f;                 // the reference's default: pow as x * sqrt(x)
-    const bool al = (d & 3u) == 0 && aligned16(pred_scores);
+    const bool al = d % PredIO<T>::VEC == 0 && aligned16(pred_scores);
     float *partials = out_loss ? (float *)workspace : nullptr;
-    auto launch = [&](auto kernel, float4 *gb, float *gs) {
+    auto launch = [&](auto kernel, box_t *gb, T *gs) {
         hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(ME_TILE), 0, st, (const float4 *)anchors,
                            (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w, neg_thr, pos_thr,
-                           (const float4 *)pred_boxes, pred_scores, lp, grad_scale, gb, gs, partials, (uint32_t)tiles,
+                           (const box_t *)pred_boxes, pred_scores, lp, grad_scale, gb, gs, partials, (uint32_t)tiles,
                            magic);
     };
-    auto pick = [&](auto grads, float4 *gb, float *gs) {
+    auto pick = [&](auto grads, box_t *gb, T *gs) {
         constexpr bool GR = decltype(grads)::value;
-        if (g15) { if (al) launch(match_loss_kernel<GR, true, true>, gb, gs); else launch(match_loss_kernel<GR, true, false>, gb, gs); }
-        else     { if (al) launch(match_loss_kernel<GR, false, true>, gb, gs); else launch(match_loss_kernel<GR, false, false>, gb, gs); }
+        if (g15) { if (al) launch(match_loss_kernel<T, GR, true, true>, gb, gs); else launch(match_loss_kernel<T, GR, true, false>, gb, gs); }
+        else     { if (al) launch(match_loss_kernel<T, GR, false, true>, gb, gs); else launch(match_loss_kernel<T, GR, false, false>, gb, gs); }
     };
-    if (grad_scores) pick(std::true_type{}, (float4 *)grad_boxes, grad_scores);
-    else pick(std::false_type{}, (float4 *)nullptr, (float *)nullptr);
+    if (grad_scores) pick(std::true_type{}, (box_t *)grad_boxes, grad_scores);
+    else pick(std::false_type{}, (box_t *)nullptr, (T *)nullptr);
     if (int rc = launch_status("match_loss")) return rc;
     if (!out_loss) return 0;
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, st, (const float *)workspace, (uint32_t)blocks, out_loss);
     return launch_status("loss_reduce");
 }
+}  // extern "C++"
 
 int odbox_match_loss(const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B, int N, int G,
                      int C, float img_h, float img_w, float neg_thr, float pos_thr, const float *pred_boxes,
@@ -827,7 +888,7 @@ int odbox_match_loss(const float *anchors, const float *gt_boxes, const int32_t 
                      float *grad_boxes, float *grad_scores, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!out_loss) return fail(ODBOX_EINVAL, "odbox_match_loss: NULL pointer");
-    return match_loss_run("odbox_match_loss", anchors, gt_boxes, gt_labels, B, N, G, C, img_h, img_w, neg_thr, pos_thr,
+    return match_loss_run<float>("odbox_match_loss", anchors, gt_boxes, gt_labels, B, N, G, C, img_h, img_w, neg_thr, pos_thr,
                           pred_boxes, pred_scores, gamma, alpha, huber_delta, out_loss, nullptr, grad_boxes, grad_scores,
                           workspace, workspace_bytes, stream);
 }
@@ -838,9 +899,34 @@ int odbox_match_loss_backward(const float *anchors, const float *gt_boxes, const
                               const float *grad_scale, float *grad_boxes, float *grad_scores, void *stream)
 {
     if (!grad_scale || !grad_boxes || !grad_scores) return fail(ODBOX_EINVAL, "odbox_match_loss_backward: NULL pointer");
-    return match_loss_run("odbox_match_loss_backward", anchors, gt_boxes, gt_labels, B, N, G, C, img_h, img_w, neg_thr,
+    return match_loss_run<float>("odbox_match_loss_backward", anchors, gt_boxes, gt_labels, B, N, G, C, img_h, img_w, neg_thr,
                           pos_thr, pred_boxes, pred_scores, gamma, alpha, huber_delta, nullptr, grad_scale, grad_boxes,
                           grad_scores, nullptr, 0, stream);
+}
+
+int odbox_match_loss_f16(const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B, int N, int G,
+                         int C, float img_h, float img_w, float neg_thr, float pos_thr, const void *pred_boxes,
+                         const void *pred_scores, float gamma, float alpha, float huber_delta, float *out_loss,
+                         void *grad_boxes, void *grad_scores, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!out_loss) return fail(ODBOX_EINVAL, "odbox_match_loss_f16: NULL pointer");
+    return match_loss_run<_Float16>("odbox_match_loss_f16", anchors, gt_boxes, gt_labels, B, N, G, C, img_h, img_w, neg_thr,
+                                    pos_thr, (const _Float16 *)pred_boxes, (const _Float16 *)pred_scores, gamma, alpha,
+                                    huber_delta, out_loss, nullptr, (_Float16 *)grad_boxes, (_Float16 *)grad_scores,
+                                    workspace, workspace_bytes, stream);
+}
+
+int odbox_match_loss_backward_f16(const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B, int N,
+                                  int G, int C, float img_h, float img_w, float neg_thr, float pos_thr,
+                                  const void *pred_boxes, const void *pred_scores, float gamma, float alpha,
+                                  float huber_delta, const float *grad_scale, void *grad_boxes, void *grad_scores,
+                                  void *stream)
+{
+    if (!grad_scale || !grad_boxes || !grad_scores) return fail(ODBOX_EINVAL, "odbox_match_loss_backward_f16: NULL pointer");
+    return match_loss_run<_Float16>("odbox_match_loss_backward_f16", anchors, gt_boxes, gt_labels, B, N, G, C, img_h, img_w,
+                                    neg_thr, pos_thr, (const _Float16 *)pred_boxes, (const _Float16 *)pred_scores, gamma,
+                                    alpha, huber_delta, nullptr, grad_scale, (_Float16 *)grad_boxes,
+                                    (_Float16 *)grad_scores, nullptr, 0, stream);
 }
 
 size_t odbox_focal_loss_workspace(size_t n)

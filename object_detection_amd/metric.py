@@ -82,6 +82,19 @@ def focal_loss(y_true, y_pred, gamma: float = 1.5, alpha: float = 0.25, from_log
     return loss
 
 
+def _pred_dtype(pred_bboxes, pred_scores):
+    """fp16 predictions (the reference's --use_fp16 / mixed_float16 run, detection.py:296-300) go to
+    the *_f16 entry points as they are; anything else is computed from fp32 tensors."""
+    if (isinstance(pred_bboxes, torch.Tensor) and isinstance(pred_scores, torch.Tensor)
+            and pred_bboxes.dtype == torch.float16 and pred_scores.dtype == torch.float16):
+        return torch.float16
+    return torch.float32
+
+
+def _entry(lib, name, dtype):
+    return getattr(lib, name + ('_f16' if dtype == torch.float16 else ''))
+
+
 def _loss_args(lib, anchors, image_hw, gt, lab, B, N, G, C, neg, pos, pb, ps):
     return (_lib.ptr(anchors), _lib.ptr(gt), _lib.ptr(lab), B, N, G, C, float(image_hw[0]), float(image_hw[1]),
             float(neg), float(pos), _lib.ptr(pb), _lib.ptr(ps))
@@ -98,7 +111,7 @@ class _DetectionLossFn(torch.autograd.Function):
         B, N, G, C, neg, pos, gamma, alpha, delta = cfg
         out = torch.empty(4, dtype=torch.float32, device=pb.device)
         ws = _workspace(pb.device, lib.odbox_match_loss_workspace(B, N))
-        _lib.check(lib.odbox_match_loss(
+        _lib.check(_entry(lib, 'odbox_match_loss', pb.dtype)(
             *_loss_args(lib, anchors, image_hw, gt, lab, B, N, G, C, neg, pos, pb, ps),
             float(gamma), float(alpha), float(delta), _lib.ptr(out), None, None, _lib.ptr(ws), ws.numel(),
             _lib.stream_ptr()), 'odbox_match_loss')
@@ -119,7 +132,7 @@ class _DetectionLossFn(torch.autograd.Function):
         scale = (up / torch.where(out[2] != 0, out[2], torch.ones_like(out[2]))).contiguous()
         gb = torch.empty_like(pb)
         gs = torch.empty_like(ps)
-        _lib.check(lib.odbox_match_loss_backward(
+        _lib.check(_entry(lib, 'odbox_match_loss_backward', pb.dtype)(
             *_loss_args(lib, anchors, ctx.image_hw, gt, lab, B, N, G, C, neg, pos, pb, ps),
             float(gamma), float(alpha), float(delta), _lib.ptr(scale), _lib.ptr(gb), _lib.ptr(gs),
             _lib.stream_ptr()), 'odbox_match_loss_backward')
@@ -136,14 +149,18 @@ def detection_loss(anchors, image_hw, true_bboxes, true_labels, pred_bboxes, pre
     When pred_bboxes / pred_scores require grad (and grad mode is on) the two losses are
     differentiable: `.backward()` runs `odbox_match_loss_backward`.  return_grads=True instead
     returns (grad_boxes [B,N,4], grad_scores [B,N,C]) explicitly, in one launch with the losses:
-    the gradients of the two RETURNED losses w.r.t. pred_bboxes / pred_scores."""
+    the gradients of the two RETURNED losses w.r.t. pred_bboxes / pred_scores.
+
+    float16 predictions are read as they are (widened to fp32 in registers like metric.py:16-17);
+    their autograd gradients come back in float16, the explicit ones in float32."""
     lib = _lib.load()
     dev = _lib.require_gpu()
     anchors = _lib.as_dev(anchors, torch.float32, dev)
     gt = _lib.as_dev(true_bboxes, torch.float32, dev)
     lab = _lib.as_dev(true_labels, torch.int32, dev)
-    pb = _lib.as_dev(pred_bboxes, torch.float32, dev)
-    ps = _lib.as_dev(pred_scores, torch.float32, dev)
+    pdt = _pred_dtype(pred_bboxes, pred_scores)
+    pb = _lib.as_dev(pred_bboxes, pdt, dev)
+    ps = _lib.as_dev(pred_scores, pdt, dev)
     B, G = int(gt.shape[0]), int(gt.shape[1])
     N, C = int(anchors.shape[0]), int(num_classes)
     if tuple(lab.shape) != (B, G) or tuple(pb.shape) != (B, N, 4) or tuple(ps.shape) != (B, N, C):
@@ -159,13 +176,15 @@ def detection_loss(anchors, image_hw, true_bboxes, true_labels, pred_bboxes, pre
         gb = torch.empty_like(pb)
         gs = torch.empty_like(ps)
     ws = _workspace(dev, lib.odbox_match_loss_workspace(B, N))
-    _lib.check(lib.odbox_match_loss(
+    _lib.check(_entry(lib, 'odbox_match_loss', pdt)(
         *_loss_args(lib, anchors, image_hw, gt, lab, B, N, G, C, negative_overlap, positive_overlap, pb, ps),
         float(gamma), float(alpha), float(huber_delta), _lib.ptr(out), _lib.ptr(gb), _lib.ptr(gs),
         _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), 'odbox_match_loss')
     if return_grads:
         # the kernel returns gradients of the unnormalised sums; scale on the device, no sync
         inv = torch.where(out[2] != 0, 1.0 / out[2], torch.ones_like(out[2]))
+        if pdt == torch.float16:      # unnormalised sums are what fits fp16 best: scale in fp32
+            return out[0], out[1], out[2], gb.float().mul_(inv), gs.float().mul_(inv)
         return out[0], out[1], out[2], gb.mul_(inv), gs.mul_(inv)
     return out[0], out[1], out[2]
 

@@ -187,3 +187,58 @@ def test_autograd_model_metric_and_image_head():
     with torch.no_grad():
         d, c, i = mm(images, gt, lab, y, tpb, tps, tp, False)
     assert not d.requires_grad and not i.requires_grad
+
+
+# ---- fp16 predictions (the reference's --use_fp16 run: metric.py:16-17 casts them to fp32 first) ----
+# The oracle gets the SAME fp16 values widened to fp32, so the losses keep the 1e-5 bar; gradients
+# are stored in fp16 (round to nearest even): 2^-10 relative, one fp16 subnormal step absolute.
+H_RTOL, H_ATOL = 1.0 / 1024, 6e-8
+
+
+@pytest.mark.parametrize('C,offset', [(80, 0), (7, 0), (3, 0), (12, 0), (16, 3), (9, 1)])
+def test_fp16_predictions_losses_and_gradients(C, offset):
+    anchors, hw, gt, lab, pb, ps, C = _case(40 + C, B=2, C=C)
+    dev = torch.device('cuda')
+    hpb = torch.as_tensor(pb, device=dev).half()
+    flat = torch.zeros(ps.size + 8, device=dev, dtype=torch.float16)
+    hps = flat[offset:offset + ps.size].view(ps.shape)
+    hps.copy_(torch.as_tensor(ps))
+    pb32, ps32 = hpb.float().cpu().numpy(), hps.float().cpu().numpy()
+    rd, rc, rn, rgb, rgs = O.model_metric(anchors, hw, gt, lab, pb32, ps32, C, with_grads=True)
+    d, c, n = M.detection_loss(anchors, hw, gt, lab, hpb, hps, C)
+    assert float(n) == rn
+    np.testing.assert_allclose([float(d), float(c)], [rd, rc], rtol=RTOL)
+    # fp32 tensors holding the same values: same box loss to the last bit (per-anchor work), same class
+    # loss up to summation order (8 elements per 16-byte vector instead of 4)
+    d32, c32, _ = M.detection_loss(anchors, hw, gt, lab, pb32, ps32, C)
+    assert float(d32) == float(d)
+    np.testing.assert_allclose(float(c32), float(c), rtol=2e-6)
+    # backward entry point with a loss scale, as fp16 training uses
+    tpb = hpb.clone().requires_grad_(True)
+    tps = hps.detach().requires_grad_(True)
+    d, c, n = M.detection_loss(anchors, hw, gt, lab, tpb, tps, C)
+    (1024.0 * (d + 0.5 * c)).backward()
+    assert tpb.grad.dtype == torch.float16 and tps.grad.dtype == torch.float16
+    np.testing.assert_allclose(tpb.grad.float().cpu().numpy(), 1024.0 * rgb / rn, rtol=H_RTOL, atol=H_ATOL)
+    np.testing.assert_allclose(tps.grad.float().cpu().numpy(), 512.0 * rgs / rn, rtol=H_RTOL, atol=H_ATOL)
+    assert torch.isfinite(tps.grad).all()
+    # explicit gradients from the forward launch
+    _, _, _, gb, gs = M.detection_loss(anchors, hw, gt, lab, hpb, hps, C, return_grads=True)
+    np.testing.assert_allclose(gb.cpu().numpy() * rn, rgb, rtol=H_RTOL, atol=H_ATOL)
+    np.testing.assert_allclose(gs.cpu().numpy() * rn, rgs, rtol=H_RTOL, atol=H_ATOL)
+    # nothing outside the view was written
+    assert (flat[:offset] == 0).all() and (flat[offset + ps.size:] == 0).all()
+
+
+def test_fp16_cfg2_full_batch():
+    anchors = O.yolo_shaped_anchors(416)
+    gt, lab = workloads.match_inputs(2)
+    rng = np.random.default_rng(1)
+    N = anchors.shape[0]
+    dev = torch.device('cuda')
+    hpb = torch.as_tensor(rng.normal(0, 1, (64, N, 4)).astype(F), device=dev).half()
+    hps = torch.as_tensor(rng.uniform(0.02, 0.98, (64, N, 80)).astype(F), device=dev).half()
+    d, c, n = M.detection_loss(anchors, (416, 416), gt, lab, hpb, hps, 80)
+    rd, rc, rn = O.model_metric(anchors, (416, 416), gt, lab, hpb.float().cpu().numpy(), hps.float().cpu().numpy(), 80)
+    assert float(n) == rn
+    np.testing.assert_allclose([float(d), float(c)], [rd, rc], rtol=RTOL)

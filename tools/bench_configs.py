@@ -119,6 +119,26 @@ def main():
         byts = B * (N * (32 + 4 * C) + 20 * G) * 2
         rows.append(dict(cfg='2_loss_backward', B=B, N=N, G=G, C=C, us=t * 1e6, img_s=B / t, GBs=byts / t / 1e9,
                          frac_hbm=byts / t / 1e9 / HBM))
+        # fp16 predictions and gradients (the reference's --use_fp16 run): half the stream
+        hb, hs = pb.half(), ps.half()
+        ghb, ghs = torch.empty_like(hb), torch.empty_like(hs)
+
+        def step_h_fwd():
+            rc = lib.odbox_match_loss_f16(anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C, float(c['S']),
+                                          float(c['S']), 0.4, 0.5, hb.data_ptr(), hs.data_ptr(), 1.5, 0.25, 1.0,
+                                          out.data_ptr(), None, None, ws.data_ptr(), ws.numel(), st)
+            assert rc == 0
+
+        def step_h_bwd():
+            rc = lib.odbox_match_loss_backward_f16(anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C,
+                                                   float(c['S']), float(c['S']), 0.4, 0.5, hb.data_ptr(), hs.data_ptr(),
+                                                   1.5, 0.25, 1.0, scale.data_ptr(), ghb.data_ptr(), ghs.data_ptr(), st)
+            assert rc == 0
+        for name, fn, mult in (('2_loss_fwd_f16', step_h_fwd, 1), ('2_loss_backward_f16', step_h_bwd, 2)):
+            t = event_time(fn, args.iters)
+            byts = B * (N * 16 + mult * N * (8 + 2 * C) + 20 * G)
+            rows.append(dict(cfg=name, B=B, N=N, G=G, C=C, us=t * 1e6, img_s=B / t, GBs=byts / t / 1e9,
+                             frac_hbm=byts / t / 1e9 / HBM))
     # COCO matching of the gathered detections of one cfg-5 eval batch (512 images)
     if 6 in args.cfg:
         import ctypes
