@@ -192,7 +192,37 @@ def main():
                              'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
                              'bytes_per_launch': byt,
                              'traffic': load_traffic('match_loss_kernel_fwd' if g1 is None else 'match_loss_kernel_fwd_bwd')}}
-        del pb, ps, gb, gs
+        # the autograd backward launch (gradients only, scaled on the device) and the fp16 variants
+        scale2 = torch.tensor([0.5, 0.25], device=dev)
+        hb, hs = pb.half(), ps.half()
+        ghb, ghs = torch.empty_like(hb), torch.empty_like(hs)
+        common = (anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C, float(S), float(S), 0.4, 0.5)
+
+        def bwd_step():
+            _lib.check(lib.odbox_match_loss_backward(*common, pb.data_ptr(), ps.data_ptr(), 1.5, 0.25, 1.0,
+                                                     scale2.data_ptr(), gb.data_ptr(), gs.data_ptr(), stream), 'backward')
+
+        def fwd16_step():
+            _lib.check(lib.odbox_match_loss_f16(*common, hb.data_ptr(), hs.data_ptr(), 1.5, 0.25, 1.0, out4.data_ptr(),
+                                                None, None, ws.data_ptr(), ws.numel(), stream), 'forward_f16')
+
+        def bwd16_step():
+            _lib.check(lib.odbox_match_loss_backward_f16(*common, hb.data_ptr(), hs.data_ptr(), 1.5, 0.25, 1.0,
+                                                         scale2.data_ptr(), ghb.data_ptr(), ghs.data_ptr(), stream),
+                       'backward_f16')
+        fixed = B * (N * 16 + 20 * G)                                          # anchors + ground truth, always fp32
+        for name, fn, byt in (('backward', bwd_step, fixed + 2 * B * N * (16 + 4 * C)),
+                              ('forward_f16', fwd16_step, fixed + B * N * (8 + 2 * C)),
+                              ('backward_f16', bwd16_step, fixed + 2 * B * N * (8 + 2 * C))):
+            wl, el = timed(fn, args.loss_steps, 5, world)
+            ach = byt / (el / args.loss_steps) / 1e9
+            result['match_loss'][name] = {
+                'value': round(world * B * args.loss_steps / wl, 1), 'unit': 'images/s',
+                'us_per_step': round(el / args.loss_steps * 1e6, 2), 'steps': args.loss_steps,
+                'roofline': {'bound': 'hbm', 'kernel': 'match_loss_kernel', 'achieved': round(ach, 1),
+                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
+                             'bytes_per_launch': byt, 'traffic': None}}
+        del pb, ps, gb, gs, hb, hs, ghb, ghs
 
     # ---------------- decode + NMS, configs[4] per-GPU share -------------------------------
     if not args.no_nms:
