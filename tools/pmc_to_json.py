@@ -19,8 +19,8 @@ for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
             name = r['Kernel_Name']
             for k, pat in (('match_loss_kernel_fwd', 'match_loss_kernel<float, false'),
                            ('match_loss_kernel_fwd_bwd', 'match_loss_kernel<float, true'),
-                           ('match_loss_kernel_f16_fwd', 'match_loss_kernel<_Float16, false'),
-                           ('match_loss_kernel_f16_bwd', 'match_loss_kernel<_Float16, true'),
+                           ('match_loss_kernel_f16_fwd', 'match_loss_kernelIDF16_Lb0'),     # rocprofv3 leaves _Float16
+                           ('match_loss_kernel_f16_bwd', 'match_loss_kernelIDF16_Lb1'),     # instantiations mangled
                            ('match_encode_kernel', 'match_encode_kernel'), ('score_scan_kernel', 'score_scan_kernel'),
                            ('nms_kernel', 'nms_kernel'), ('finalize_kernel', 'finalize_kernel'),
                            ('cand_partition_kernel', 'cand_partition_kernel')):
