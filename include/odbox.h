@@ -64,12 +64,15 @@ int odbox_match_encode(const float *anchors /*[N,4]*/, const float *gt_boxes /*[
  * focal_loss (metric.py:9-38: clip to [1e-6, 1-1e-6], alpha_t, pow(1-pt, gamma), log) and
  * tf.keras.losses.Huber(delta, reduction=SUM) evaluated straight from the match, so neither
  * [B,N,C+1] nor [B,N,5] is ever materialised.
- * out_loss[4] = { dist_loss, class_loss, npos, 0 }: both losses divided by npos (the number of
- * foreground anchors) when npos != 0, exactly like metric.py:108-123.
+ * out_loss[4] = { dist_loss, class_loss, npos, hits }: both losses divided by npos (the number of
+ * foreground anchors) when npos != 0, exactly like metric.py:108-123; hits = the number of
+ * foreground anchors whose highest predicted class (first maximum) is the matched class, i.e.
+ * hits / npos is the CategoricalAccuracy that metric.py:128-130 accumulates.
  * grad_boxes [B,N,4] / grad_scores [B,N,C] (both or neither): gradients of the UNNORMALISED sums
  * w.r.t. pred_boxes / pred_scores (zero for ignored anchors, background boxes and clipped
  * scores); divide by npos to get the gradients of the returned losses.
- * pred_scores are probabilities (the reference calls focal_loss with from_logits=False). */
+ * pred_scores are probabilities (the reference calls focal_loss with from_logits=False).
+ * workspace: odbox_match_loss_workspace(B, N) bytes, 16-byte aligned. */
 size_t odbox_match_loss_workspace(int B, int N);
 int odbox_match_loss(const float *anchors /*[N,4]*/, const float *gt_boxes /*[B,G,4]*/,
                      const int32_t *gt_labels /*[B,G]*/, int B, int N, int G, int C,

@@ -466,8 +466,9 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     using IO = PredIO<T>;
     constexpr uint32_t VEC = IO::VEC;
     typedef typename IO::vec_t vec_t;
-    __shared__ float s_live[ME_TILE];           // 1.0 = anchor counts (state != -1), 0.0 = ignored
-    __shared__ float s_red[3][ME_TILE / WAVE];
+    __shared__ float s_live[ME_TILE];           // |x| = 1.0: anchor counts (state != -1), 0.0 = ignored; -1.0 = foreground
+    __shared__ float s_red[4][ME_TILE / WAVE];
+    __shared__ unsigned long long s_top[ME_TILE];   // per foreground anchor: (ordered top score, ~class), LDS atomic max
 
     // backward entry point: gradients times two device-resident factors (box, score) -- the
     // 1 / npos normaliser and the upstream gradient folded in, so no second pass over [B,N,C]
@@ -498,7 +499,17 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     if (d >= VEC && nvec) cur = pv4[min(tid, nvec - 1)];
 
     const TileMatch tm = match_tile<ME_TILE>(anchors, gt_boxes, gt_labels, b, n0, N, G, C, img_h, img_w, neg_thr, pos_thr);
-    s_live[tid] = tm.live && tm.state != -1 ? 1.0f : 0.0f;
+    s_live[tid] = tm.live && tm.state != -1 ? (tm.state == 1 ? -1.0f : 1.0f) : 0.0f;
+    s_top[tid] = 0ull;
+    // metric.py:128-130 (CategoricalAccuracy over the foreground anchors) rides on the stream: a
+    // thread whose vector lies in a foreground row folds its elements into that row's (score, class)
+    // maximum; forward launches only
+    const bool want_hits = partials != nullptr;
+    auto top_key = [](float x, uint32_t col) -> unsigned long long {
+        uint32_t u = __float_as_uint(x + 0.0f);                      // -0 -> +0: equal scores must tie
+        u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;                  // order-preserving bits
+        return ((unsigned long long)u << 32) | (0xffffffffu - col);  // ties: the lower class wins (tf.argmax)
+    };
 
     // the one y = 1 element of a foreground anchor: fetch it now, correct the sum after the stream
     const bool has_pos = tm.live && tm.state == 1 && tm.label >= 0;
@@ -542,9 +553,12 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
         auto one = [&](uint32_t e) {
             uint32_t q, r;
             divmod_u32(e, d, c_magic, q, r);
-            const float m = s_live[q];
+            const float lv = s_live[q];
+            const float m = fabsf(lv);
             float g = 0.0f;
-            cls += m * focal_neg<G15, GRADS>((float)p[e], lp, cneg, g);
+            const float x = (float)p[e];
+            if (want_hits && lv < 0.0f) atomicMax(&s_top[q], top_key(x, r));
+            cls += m * focal_neg<G15, GRADS>(x, lp, cneg, g);
             if (GRADS) gp[e] = (T)(g * (m * gs_cls));       // m is exactly 0 or 1
         };
         if (tid < head) one(tid);
@@ -554,9 +568,18 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
                 const uint32_t e = head + VEC * v;
                 uint32_t q, r;
                 divmod_u32(e, d, c_magic, q, r);
-                const float m0 = s_live[q];
+                const float lv0 = s_live[q];
+                const float m0 = fabsf(lv0);
                 float in[VEC], g[VEC], l[VEC];
                 IO::unpack(cur, in);
+                if (ALIGNED && want_hits && lv0 < 0.0f) {
+                    float bx = in[0];
+                    uint32_t bk = 0;
+#pragma unroll
+                    for (uint32_t k = 1; k < VEC; ++k)
+                        if (in[k] > bx) { bx = in[k]; bk = k; }
+                    atomicMax(&s_top[q], top_key(bx, r + bk));
+                }
 #pragma unroll
                 for (uint32_t k = 0; k < VEC; ++k) {
                     g[k] = 0.0f;
@@ -570,8 +593,17 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
                     for (uint32_t k = 0; k < VEC; ++k) g[k] *= m0 * gs_cls;
                 } else {
                     // a 16-byte vector spans at most two anchors (d >= VEC): q (elements k < left) and q + 1
-                    const float m1 = s_live[min(q + 1, (uint32_t)ME_TILE - 1)];
+                    const uint32_t q1 = min(q + 1, (uint32_t)ME_TILE - 1);
+                    const float lv1 = s_live[q1];
+                    const float m1 = fabsf(lv1);
                     const uint32_t left = d - r;
+                    if (want_hits && (lv0 < 0.0f || lv1 < 0.0f)) {
+#pragma unroll
+                        for (uint32_t k = 0; k < VEC; ++k) {
+                            const bool first = k < left;
+                            if ((first ? lv0 : lv1) < 0.0f) atomicMax(&s_top[first ? q : q1], top_key(in[k], first ? r + k : k - left));
+                        }
+                    }
 #pragma unroll
                     for (uint32_t k = 0; k < VEC; ++k) {
                         const float m = k < left ? m0 : m1;
@@ -596,37 +628,39 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     }
 
     // ---- the matched class of every foreground anchor: replace its y = 0 term by the y = 1 term ---
+    float hit = 0.0f;
     {
         float g0 = 0.0f, g1 = 0.0f;
         const float lneg = focal_neg<G15, GRADS>(pos_x, lp, cneg, g0);
         const float lpos = focal_term<G15, GRADS>(pos_x, true, lp, g1);
         if (has_pos) cls += lpos - lneg;
-        if (GRADS) {
-            __syncthreads();                     // the streaming stores of this tile are done
-            if (has_pos) gp[pos_e] = (T)(g1 * gs_cls);
-        }
+        if (GRADS || want_hits) __syncthreads();     // the streaming stores / LDS maxima of this tile are done
+        if (GRADS && has_pos) gp[pos_e] = (T)(g1 * gs_cls);
+        // an out-of-range label is an all-zero one-hot row, whose argmax is class 0
+        if (want_hits && tm.live && tm.state == 1)
+            hit = 0xffffffffu - (uint32_t)s_top[tid] == (uint32_t)max(tm.label, 0) ? 1.0f : 0.0f;
     }
 
     // ---- block partial sums (wave shuffle, then one thread adds the 4 wave sums in order) ------
-    float v3[3] = {cls, dist, npos};
+    float v3[4] = {cls, dist, npos, hit};
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 4; ++k) {
         float x = v3[k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
         if ((tid & 63u) == 0) s_red[k][tid >> 6] = x;
     }
     __syncthreads();
-    if (tid < 3 && partials) {
+    if (tid < 4 && partials) {
         float x = 0.0f;
         for (int w = 0; w < ME_TILE / WAVE; ++w) x += s_red[tid][w];
-        partials[(size_t)blk * 3 + tid] = x;
+        partials[(size_t)blk * 4 + tid] = x;
     }
 }
 
 // metric.py:9-38 focal_loss on dense targets (y_true == 1 marks the positive class), summed over
 // all n elements; used for the whole-image classifier head (metric.py:132-134).  Per-block
-// partials in slot 0 of the [nblocks, 3] buffer.
+// partials in slot 0 of the [nblocks, 4] buffer.
 template <bool G15>
 __global__ __launch_bounds__(256) void focal_dense_kernel(const float *__restrict__ y_true,
                                                           const float *__restrict__ y_pred, size_t n, LossParams lp,
@@ -644,55 +678,56 @@ __global__ __launch_bounds__(256) void focal_dense_kernel(const float *__restric
     if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        partials[(size_t)blockIdx.x * 3 + 0] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
-        partials[(size_t)blockIdx.x * 3 + 1] = 0.0f;
-        partials[(size_t)blockIdx.x * 3 + 2] = 0.0f;
+        partials[(size_t)blockIdx.x * 4 + 0] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+        partials[(size_t)blockIdx.x * 4 + 1] = 0.0f;
+        partials[(size_t)blockIdx.x * 4 + 2] = 0.0f;
+        partials[(size_t)blockIdx.x * 4 + 3] = 0.0f;
     }
 }
 
-// partials [nblocks, 3] (class_sum, dist_sum, npos) -> out[0] = dist_loss, out[1] = class_loss (both
-// divided by npos when npos != 0, metric.py:121-123), out[2] = npos, out[3] = 0; sums in double,
-// fixed order.
+// partials [nblocks, 4] (class_sum, dist_sum, npos, hits) -> out[0] = dist_loss, out[1] = class_loss
+// (both divided by npos when npos != 0, metric.py:121-123), out[2] = npos, out[3] = hits (foreground
+// anchors whose top predicted class is the matched one); sums in double, fixed order.
 constexpr int RED_THREADS = 1024;
-__global__ __launch_bounds__(RED_THREADS) void loss_reduce_kernel(const float *__restrict__ partials, uint32_t nblocks,
+__global__ __launch_bounds__(RED_THREADS) void loss_reduce_kernel(const float4 *__restrict__ partials, uint32_t nblocks,
                                                                   float *__restrict__ out)
 {
     // One block; a single-block kernel is pure latency, so every thread issues its loads back to
     // back (4 rows per trip) before the first add.  Thread t owns rows t, t + 1024, ...: the
     // summation tree is fixed by (nblocks), not by scheduling.
-    __shared__ double s_acc[3][RED_THREADS / WAVE];
-    double acc[3] = {0.0, 0.0, 0.0};
+    __shared__ double s_acc[4][RED_THREADS / WAVE];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
     for (uint32_t i0 = threadIdx.x; i0 < nblocks; i0 += 4 * RED_THREADS) {
-        float v[4][3];
+        float4 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t i = i0 + (uint32_t)u * RED_THREADS;
-            const bool ok = i < nblocks;
-            const size_t at = (size_t)(ok ? i : i0) * 3;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) v[u][k] = ok ? partials[at + k] : 0.0f;
+            v[u] = i < nblocks ? partials[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) acc[k] += (double)v[u][k];
+        for (int u = 0; u < 4; ++u) {
+            acc[0] += (double)v[u].x;
+            acc[1] += (double)v[u].y;
+            acc[2] += (double)v[u].z;
+            acc[3] += (double)v[u].w;
+        }
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 4; ++k) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off);
         if ((threadIdx.x & 63u) == 0) s_acc[k][threadIdx.x >> 6] = acc[k];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double t[3] = {0.0, 0.0, 0.0};
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
         for (int w = 0; w < RED_THREADS / WAVE; ++w)
-            for (int k = 0; k < 3; ++k) t[k] += s_acc[k][w];
+            for (int k = 0; k < 4; ++k) t[k] += s_acc[k][w];
         const double cls = t[0], dist = t[1], npos = t[2];
         out[0] = (float)(npos != 0.0 ? dist / npos : dist);
         out[1] = (float)(npos != 0.0 ? cls / npos : cls);
         out[2] = (float)npos;
-        out[3] = 0.0f;
+        out[3] = (float)t[3];
     }
 }
 
@@ -819,7 +854,7 @@ size_t odbox_match_loss_workspace(int B, int N)
 {
     if (B < 1 || N < 1) return 0;
     const size_t tiles = ((size_t)N + ME_TILE - 1) / ME_TILE;
-    return (tiles * (size_t)B * 3 * sizeof(float) + 255) / 256 * 256;
+    return (tiles * (size_t)B * 4 * sizeof(float) + 255) / 256 * 256;
 }
 
 // Shared by odbox_match_loss (out_loss + optional unscaled gradients) and odbox_match_loss_backward
@@ -851,6 +886,7 @@ static int match_loss_run(const char *name, const float *anchors, const float *g
         const size_t need = odbox_match_loss_workspace(B, N);
         if (!workspace || workspace_bytes < need)
             return fail(ODBOX_ENOSPC, "%s: workspace %zu bytes, need %zu", name, workspace_bytes, need);
+        if (!aligned16(workspace)) return fail(ODBOX_EINVAL, "%s: workspace must be 16-byte aligned", name);
     }
     const uint64_t tiles = ((uint64_t)N + ME_TILE - 1) / ME_TILE;
     const uint64_t blocks = tiles * (uint64_t)B;
@@ -877,7 +913,7 @@ static int match_loss_run(const char *name, const float *anchors, const float *g
     else pick(std::false_type{}, (box_t *)nullptr, (T *)nullptr);
     if (int rc = launch_status("match_loss")) return rc;
     if (!out_loss) return 0;
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, st, (const float *)workspace, (uint32_t)blocks, out_loss);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, st, (const float4 *)workspace, (uint32_t)blocks, out_loss);
     return launch_status("loss_reduce");
 }
 }  // extern "C++"
@@ -934,7 +970,7 @@ size_t odbox_focal_loss_workspace(size_t n)
     size_t blocks = (n + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    return (blocks * 3 * sizeof(float) + 255) / 256 * 256;
+    return (blocks * 4 * sizeof(float) + 255) / 256 * 256;
 }
 
 int odbox_focal_loss(const float *y_true, const float *y_pred, size_t n, float gamma, float alpha, float *out_sum,
@@ -945,6 +981,7 @@ int odbox_focal_loss(const float *y_true, const float *y_pred, size_t n, float g
     const size_t need = odbox_focal_loss_workspace(n);
     if (!workspace || workspace_bytes < need)
         return fail(ODBOX_ENOSPC, "odbox_focal_loss: workspace %zu bytes, need %zu", workspace_bytes, need);
+    if (!aligned16(workspace)) return fail(ODBOX_EINVAL, "odbox_focal_loss: workspace must be 16-byte aligned");
     size_t blocks = (n + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
@@ -957,9 +994,9 @@ int odbox_focal_loss(const float *y_true, const float *y_pred, size_t n, float g
         hipLaunchKernelGGL(focal_dense_kernel<false>, dim3((uint32_t)blocks), dim3(256), 0, st, y_true, y_pred, n, lp, grad,
                            (float *)workspace);
     if (int rc = launch_status("focal_dense")) return rc;
-    // reuse the 3-slot reducer: slot 0 holds the sum, npos slot is 0 so nothing is divided; the
+    // reuse the 4-slot reducer: slot 0 holds the sum, npos slot is 0 so nothing is divided; the
     // sum comes out in out[1]; out_sum must therefore have room for 4 floats
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, st, (const float *)workspace, (uint32_t)blocks, out_sum);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, st, (const float4 *)workspace, (uint32_t)blocks, out_sum);
     return launch_status("loss_reduce");
 }
 

@@ -4,9 +4,11 @@ of the box targets, fused with the matcher so the one-hot `[B,N,C+1]` label tens
 
 `ModelMetric(all_anchors, num_classes)(images, true_bboxes, true_labels, true_image_labels,
 pred_bboxes, pred_scores, pred_image_scores, training)` returns
-`(dist_loss, class_loss, image_class_loss)` like metric.py:97-138 (device scalars).  The Keras
-running means / accuracies of the reference's `Metric` class are bookkeeping, not arithmetic on
-the path, and are not reproduced.  HIP only (odbox_match_loss / odbox_focal_loss), no CPU fallback.
+`(dist_loss, class_loss, image_class_loss)` like metric.py:97-138 (device scalars) and keeps the
+reference's running statistics in `train_metric` (`Metric`, metric.py:40-73): means of the losses
+and the two categorical accuracies, accumulated on the device without a host sync; the foreground
+accuracy's numerator comes out of the same kernel launch as the losses (out_loss[3]).
+HIP only (odbox_match_loss / odbox_focal_loss), no CPU fallback.
 """
 import torch
 
@@ -117,12 +119,12 @@ class _DetectionLossFn(torch.autograd.Function):
             _lib.stream_ptr()), 'odbox_match_loss')
         ctx.save_for_backward(pb, ps, anchors, gt, lab, out)
         ctx.image_hw, ctx.cfg = image_hw, cfg
-        dist, cls, npos = out[0], out[1], out[2]
-        ctx.mark_non_differentiable(npos)
-        return dist, cls, npos
+        dist, cls, npos, hits = out[0], out[1], out[2], out[3]
+        ctx.mark_non_differentiable(npos, hits)
+        return dist, cls, npos, hits
 
     @staticmethod
-    def backward(ctx, g_dist, g_cls, _g_npos):
+    def backward(ctx, g_dist, g_cls, _g_npos, _g_hits):
         lib = _lib.load()
         pb, ps, anchors, gt, lab, out = ctx.saved_tensors
         B, N, G, C, neg, pos, gamma, alpha, delta = ctx.cfg
@@ -141,7 +143,7 @@ class _DetectionLossFn(torch.autograd.Function):
 
 def detection_loss(anchors, image_hw, true_bboxes, true_labels, pred_bboxes, pred_scores, num_classes,
                    negative_overlap=0.4, positive_overlap=0.5, gamma=1.5, alpha=0.25, huber_delta=1.0,
-                   return_grads=False):
+                   return_grads=False, return_hits=False):
     """The fused matcher + loss (`odbox_match_loss`).  Returns (dist_loss, class_loss, normalizer)
     as device scalars, both losses divided by normalizer = #foreground anchors when it is not 0
     (metric.py:108-123).
@@ -152,7 +154,10 @@ def detection_loss(anchors, image_hw, true_bboxes, true_labels, pred_bboxes, pre
     the gradients of the two RETURNED losses w.r.t. pred_bboxes / pred_scores.
 
     float16 predictions are read as they are (widened to fp32 in registers like metric.py:16-17);
-    their autograd gradients come back in float16, the explicit ones in float32."""
+    their autograd gradients come back in float16, the explicit ones in float32.
+
+    return_hits=True appends the number of foreground anchors whose top predicted class is the
+    matched class (hits / normalizer = the CategoricalAccuracy of metric.py:128-130)."""
     lib = _lib.load()
     dev = _lib.require_gpu()
     anchors = _lib.as_dev(anchors, torch.float32, dev)
@@ -168,7 +173,8 @@ def detection_loss(anchors, image_hw, true_bboxes, true_labels, pred_bboxes, pre
                          % (tuple(lab.shape), tuple(pb.shape), tuple(ps.shape), B, N, G, C))
     if not return_grads and torch.is_grad_enabled() and (pb.requires_grad or ps.requires_grad):
         cfg = (B, N, G, C, negative_overlap, positive_overlap, gamma, alpha, huber_delta)
-        return _DetectionLossFn.apply(pb, ps, anchors.detach(), gt.detach(), lab, (float(image_hw[0]), float(image_hw[1])), cfg)
+        res = _DetectionLossFn.apply(pb, ps, anchors.detach(), gt.detach(), lab, (float(image_hw[0]), float(image_hw[1])), cfg)
+        return res if return_hits else res[:3]
     pb, ps = pb.detach(), ps.detach()
     out = torch.empty(4, dtype=torch.float32, device=dev)
     gb = gs = None
@@ -184,9 +190,64 @@ def detection_loss(anchors, image_hw, true_bboxes, true_labels, pred_bboxes, pre
         # the kernel returns gradients of the unnormalised sums; scale on the device, no sync
         inv = torch.where(out[2] != 0, 1.0 / out[2], torch.ones_like(out[2]))
         if pdt == torch.float16:      # unnormalised sums are what fits fp16 best: scale in fp32
-            return out[0], out[1], out[2], gb.float().mul_(inv), gs.float().mul_(inv)
-        return out[0], out[1], out[2], gb.mul_(inv), gs.mul_(inv)
-    return out[0], out[1], out[2]
+            res = (out[0], out[1], out[2], gb.float().mul_(inv), gs.float().mul_(inv))
+        else:
+            res = (out[0], out[1], out[2], gb.mul_(inv), gs.mul_(inv))
+    else:
+        res = (out[0], out[1], out[2])
+    return res + (out[3],) if return_hits else res
+
+
+class _Mean:
+    """tf.keras.metrics.Mean on the device: update_state never syncs, result() does."""
+
+    def __init__(self):
+        self.total = None
+        self.count = None
+
+    def reset_states(self):
+        self.total = None
+        self.count = None
+
+    def update_state(self, value, weight=1.0):
+        value = torch.as_tensor(value, dtype=torch.float32).detach()
+        weight = torch.as_tensor(weight, dtype=torch.float32, device=value.device).detach()
+        if self.total is None:
+            self.total, self.count = value.clone(), weight.clone()
+        else:
+            self.total += value
+            self.count += weight
+
+    def result(self):
+        if self.total is None:
+            return 0.0
+        c = float(self.count)
+        return float(self.total) / c if c != 0 else 0.0
+
+
+class Metric:
+    """metric.py:40-73: the running statistics the reference prints per epoch.  The means take one
+    value per step; the accuracies are hits / samples over all steps (CategoricalAccuracy)."""
+
+    def __init__(self, training=True, **kwargs):
+        self.training = training
+        self.total_loss = _Mean()
+        self.reg_loss = _Mean()
+        self.dist_loss = _Mean()
+        self.ce_loss = _Mean()
+        self.ce_image_loss = _Mean()
+        self.ce_acc = _Mean()
+        self.ce_image_acc = _Mean()
+
+    def reset_states(self):
+        for m in (self.total_loss, self.reg_loss, self.dist_loss, self.ce_loss, self.ce_image_loss, self.ce_acc,
+                  self.ce_image_acc):
+            m.reset_states()
+
+    def str_result(self):
+        return 'total_loss: {:.4f}, reg_loss: {:.3f}, dist: {:.3f}, ce: {:.3f}, image_ce: {:.3f}, acc: {:.3f}, image_acc: {:.3f}'.format(
+            self.total_loss.result(), self.reg_loss.result(), self.dist_loss.result(), self.ce_loss.result(),
+            self.ce_image_loss.result(), self.ce_acc.result(), self.ce_image_acc.result())
 
 
 class ModelMetric:
@@ -197,12 +258,29 @@ class ModelMetric:
         self.all_anchors = all_anchors
         self.num_classes = num_classes
         self.dtype = dtype
+        self.train_metric = Metric(training=True, name='train_metric')
+
+    def str_result(self, training):
+        return self.train_metric.str_result()
+
+    def reset_states(self):
+        self.train_metric.reset_states()
 
     def __call__(self, images, true_bboxes, true_labels, true_image_labels, pred_bboxes, pred_scores,
                  pred_image_scores, training):
-        dist_loss, class_loss, _ = detection_loss(self.all_anchors, _image_hw(images), true_bboxes, true_labels,
-                                                  pred_bboxes, pred_scores, self.num_classes)
+        dist_loss, class_loss, npos, hits = detection_loss(self.all_anchors, _image_hw(images), true_bboxes,
+                                                           true_labels, pred_bboxes, pred_scores, self.num_classes,
+                                                           return_hits=True)
+        m = self.train_metric
+        m.dist_loss.update_state(dist_loss)                                   # metric.py:125-126
+        m.ce_loss.update_state(class_loss)
+        m.ce_acc.update_state(hits, npos)                                     # :128-130
         image_class_loss = 0.
         if pred_image_scores is not None:
             image_class_loss = focal_loss(true_image_labels, pred_image_scores, reduction='sum')
+            m.ce_image_loss.update_state(image_class_loss)                    # :134-136
+            dev = image_class_loss.device
+            yt = torch.as_tensor(true_image_labels, device=dev)
+            yp = torch.as_tensor(pred_image_scores, device=dev).detach()
+            m.ce_image_acc.update_state((yt.argmax(-1) == yp.argmax(-1)).sum(), float(yt[..., 0].numel()))
         return dist_loss, class_loss, image_class_loss

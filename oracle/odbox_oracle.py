@@ -395,6 +395,28 @@ def model_metric(anchors, image_hw, true_bboxes, true_labels, pred_bboxes, pred_
     return dist_loss, class_loss, normalizer, gb, gs
 
 
+def foreground_accuracy(anchors, image_hw, true_bboxes, true_labels, pred_scores, num_classes):
+    """metric.py:128-130: tf.keras.metrics.CategoricalAccuracy over the foreground anchors, i.e.
+    argmax(one-hot label row) == argmax(predicted scores) with tf.argmax's first-maximum rule (an
+    all-zero one-hot row, tf.one_hot of an out-of-range label, has argmax 0).
+    Returns (hits, foreground count); the metric is their ratio."""
+    t = anchor_targets_bbox(anchors, image_hw, true_bboxes, true_labels, num_classes)
+    labels = t['labels']
+    fg = labels[:, :, -1] == F32(1)
+    y = labels[:, :, :-1][fg]
+    p = _f32(pred_scores)[fg]
+    if y.shape[0] == 0:
+        return 0, 0
+    return int((np.argmax(y, axis=-1) == np.argmax(p, axis=-1)).sum()), int(y.shape[0])
+
+
+def categorical_accuracy(y_true, y_pred):
+    """tf.keras.metrics.CategoricalAccuracy on dense rows (metric.py:136): (hits, rows)."""
+    y_true, y_pred = _f32(y_true), _f32(y_pred)
+    rows = int(np.prod(y_true.shape[:-1]))
+    return int((np.argmax(y_true, axis=-1) == np.argmax(y_pred, axis=-1)).sum()), rows
+
+
 # ----------------------------------------------------------------------------------------
 # SURVEY.md 8f row 3: ground-truth preparation feeding the matcher (detection.py)
 # ----------------------------------------------------------------------------------------

@@ -242,3 +242,52 @@ def test_fp16_cfg2_full_batch():
     rd, rc, rn = O.model_metric(anchors, (416, 416), gt, lab, hpb.float().cpu().numpy(), hps.float().cpu().numpy(), 80)
     assert float(n) == rn
     np.testing.assert_allclose([float(d), float(c)], [rd, rc], rtol=RTOL)
+
+
+@pytest.mark.parametrize('C,half', [(7, False), (80, False), (1, False), (12, True), (80, True), (5, True)])
+def test_foreground_accuracy_hits(C, half):
+    """out_loss[3]: metric.py:128-130, exact (an integer count).  Ties in the predictions go to the
+    first maximum; labels outside [0, C) count as class 0 like an all-zero one-hot row."""
+    anchors, hw, gt, lab, pb, ps, C = _case(60 + C, B=3, C=C)
+    ps[1, ::3] = 0.25                                   # whole rows tied: argmax 0
+    ps[2, 1::2, C // 2] = 0.999                         # a clear winner on every other anchor
+    lab[2, :4] = C + 3                                  # out-of-range labels on some GT rows
+    if half:
+        dev = torch.device('cuda')
+        tpb, tps = torch.as_tensor(pb, device=dev).half(), torch.as_tensor(ps, device=dev).half()
+        ps = tps.float().cpu().numpy()
+    else:
+        tpb, tps = pb, ps
+    d, c, n, hits = M.detection_loss(anchors, hw, gt, lab, tpb, tps, C, return_hits=True)
+    rh, rn = O.foreground_accuracy(anchors, hw, gt, lab, ps, C)
+    assert rn > 0 and float(n) == rn
+    assert float(hits) == rh
+    assert 0 < rh < rn or C == 1
+
+
+def test_model_metric_running_statistics():
+    rng = np.random.default_rng(9)
+    anchors, hw, gt, lab, pb, ps, C = _case(71, B=2, C=6)
+    mm = M.ModelMetric(anchors, C)
+    images = np.zeros((2, hw[0], hw[1], 3), F)
+    want_d, want_c, hits, fgs, ihits, irows, want_i = [], [], 0, 0, 0, 0, []
+    for step in range(3):
+        ps_s = rng.uniform(0, 1, ps.shape).astype(F)
+        pb_s = rng.normal(0, 1, pb.shape).astype(F)
+        y = np.eye(5, dtype=F)[rng.integers(0, 5, 2)]
+        p = rng.uniform(0.05, 0.95, (2, 5)).astype(F)
+        mm(images, gt, lab, y, pb_s, ps_s, p, True)
+        rd, rc, _ = O.model_metric(anchors, hw, gt, lab, pb_s, ps_s, C)
+        h, n = O.foreground_accuracy(anchors, hw, gt, lab, ps_s, C)
+        ih, ir = O.categorical_accuracy(y, p)
+        want_d.append(rd); want_c.append(rc); want_i.append(O.focal_loss(y, p))
+        hits += h; fgs += n; ihits += ih; irows += ir
+    t = mm.train_metric
+    np.testing.assert_allclose(t.dist_loss.result(), np.mean(want_d), rtol=RTOL)
+    np.testing.assert_allclose(t.ce_loss.result(), np.mean(want_c), rtol=RTOL)
+    np.testing.assert_allclose(t.ce_image_loss.result(), np.mean(want_i), rtol=RTOL)
+    np.testing.assert_allclose(t.ce_acc.result(), hits / fgs, rtol=1e-6)
+    np.testing.assert_allclose(t.ce_image_acc.result(), ihits / irows, rtol=1e-6)
+    assert 'acc: %.3f' % (hits / fgs) in mm.str_result(True)
+    mm.reset_states()
+    assert t.ce_acc.result() == 0.0 and t.dist_loss.result() == 0.0
