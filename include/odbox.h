@@ -228,6 +228,18 @@ int odbox_gt_prepare_poly(const float *polys /*[rows,4,2]*/, const int32_t *labe
                           float *out_boxes /*[B,max_items,4]*/, int32_t *out_labels /*[B,max_items]*/,
                           void *stream);
 
+/* ---- output side of inference: detections back to original image pixels ---- */
+
+/* infdet.py:140-174 (run_eval's per-detection loop): the model saw the image padded to a square
+ * and resized to image_size; per image  max_side = max(imh, imw), pad = (max_side - im{h,w}) / 2,
+ * square_scale = max_side / image_size, and each box  bb.astype(float) * square_scale  with
+ * pad_x / pad_y subtracted -- Python floats, so fp64 here, bit for bit.  The loop stops at the
+ * first score <= 0 (:161-162): out_count[b] = that index, rows from there on are written as 0.
+ * orig_hw [B,2] int32 = (height, width) of the original image (cv2 image.shape[:2]). */
+int odbox_restore_boxes(const float *boxes /*[B,R,4]*/, const float *scores /*[B,R]*/,
+                        const int32_t *orig_hw /*[B,2]*/, int B, int R, int image_size,
+                        double *out_boxes /*[B,R,4] f64*/, int32_t *out_count /*[B]*/, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

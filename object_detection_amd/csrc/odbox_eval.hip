@@ -464,6 +464,44 @@ int gt_prepare(const char *name, bool from_xywh, const float *src, const int32_t
     return launch_status(name);
 }
 
+// ------------------------------------------------------------------------------------------
+// infdet.py:140-174  detections of the padded, resized square back to original image pixels:
+//   max_side = max(imh, imw); pad = (max_side - im{h,w}) / 2; square_scale = max_side / image_size
+//   bb.astype(float) * square_scale, then x -= pad_x, y -= pad_y          (all Python floats: fp64)
+// and the per-image loop stops at the first score <= 0 (:161-162).  One block per image.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void restore_boxes_kernel(const float4 *__restrict__ boxes,
+                                                            const float *__restrict__ scores,
+                                                            const int32_t *__restrict__ orig_hw, int R, double image_size,
+                                                            double *__restrict__ out, int32_t *__restrict__ out_count)
+{
+    __shared__ int s_first;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) s_first = R;
+    __syncthreads();
+    int first = R;
+    for (int r = threadIdx.x; r < R; r += 256)
+        if (scores[(size_t)b * R + r] <= 0.0f) { first = r; break; }        // `if score <= 0: break`
+    if (first < R) atomicMin(&s_first, first);
+    __syncthreads();
+    const int count = s_first;
+    const double imh = (double)orig_hw[2 * b], imw = (double)orig_hw[2 * b + 1];
+    const double max_side = imh > imw ? imh : imw;
+    const double pad_y = (max_side - imh) / 2.0, pad_x = (max_side - imw) / 2.0;
+    const double square_scale = max_side / image_size;
+    for (int r = threadIdx.x; r < R; r += 256) {
+        double4 o = make_double4(0.0, 0.0, 0.0, 0.0);
+        if (r < count) {
+            const float4 v = boxes[(size_t)b * R + r];
+            o = make_double4((double)v.x * square_scale - pad_x, (double)v.y * square_scale - pad_y,
+                             (double)v.z * square_scale - pad_x, (double)v.w * square_scale - pad_y);
+        }
+        double *dst = out + ((size_t)b * R + r) * 4;
+        dst[0] = o.x; dst[1] = o.y; dst[2] = o.z; dst[3] = o.w;
+    }
+    if (threadIdx.x == 0) out_count[b] = count;
+}
+
 }  // namespace
 
 extern "C" {
@@ -482,6 +520,21 @@ int odbox_gt_prepare_poly(const float *polys, const int32_t *labels, const int32
 {
     return gt_prepare("odbox_gt_prepare_poly", false, polys, labels, row_offsets, canvas_size, B, max_items, image_size,
                       half_round, mode, out_boxes, out_labels, stream);
+}
+
+int odbox_restore_boxes(const float *boxes, const float *scores, const int32_t *orig_hw, int B, int R, int image_size,
+                        double *out_boxes, int32_t *out_count, void *stream)
+{
+    if (B < 0 || R < 0 || image_size < 1)
+        return fail(ODBOX_EINVAL, "odbox_restore_boxes: bad shape B=%d R=%d image_size=%d", B, R, image_size);
+    if (B == 0) return 0;
+    if (!orig_hw || !out_count || (R > 0 && (!boxes || !scores || !out_boxes)))
+        return fail(ODBOX_EINVAL, "odbox_restore_boxes: NULL pointer");
+    if (((uintptr_t)boxes & 15u) || ((uintptr_t)out_boxes & 7u))
+        return fail(ODBOX_EINVAL, "odbox_restore_boxes: boxes must be 16-byte aligned, out_boxes 8-byte");
+    hipLaunchKernelGGL(restore_boxes_kernel, dim3((uint32_t)B), dim3(256), 0, (hipStream_t)stream, (const float4 *)boxes,
+                       scores, orig_hw, R, (double)image_size, out_boxes, out_count);
+    return launch_status("restore_boxes");
 }
 
 }  // extern "C"

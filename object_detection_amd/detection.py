@@ -91,3 +91,39 @@ def polygon2bbox(poly, want_yx=False, want_wh=False):
     one = torch.ones(1, dtype=torch.float32, device=dev)            # canvas 1 -> size 1: coordinates unchanged
     boxes, _ = _launch('odbox_gt_prepare_poly', p, lab, offs, one, 1, 1.0, n, dtype, want_yx, want_wh)
     return boxes[0]
+
+
+def restore_detections(coords_batch, scores_batch, orig_hw, image_size: int):
+    """infdet.py:140-174 for a whole batch in one launch (`odbox_restore_boxes`): detections of the
+    padded, resized square back to original image pixels, in float64 like the reference's Python
+    floats.  coords_batch [B,R,4] / scores_batch [B,R] as `bndbox.nms` returns them, orig_hw [B,2]
+    = (height, width) of each original image.  Returns (boxes [B,R,4] float64 on the device, zero
+    from the first score <= 0 on, counts [B] int32 = where the reference's loop breaks)."""
+    lib = _lib.load()
+    dev = _lib.require_gpu()
+    boxes = _lib.as_dev(coords_batch, torch.float32, dev)
+    scores = _lib.as_dev(scores_batch, torch.float32, dev)
+    hw = _lib.as_dev(orig_hw, torch.int32, dev)
+    B, R = int(scores.shape[0]), int(scores.shape[1])
+    if tuple(boxes.shape) != (B, R, 4) or tuple(hw.shape) != (B, 2):
+        raise ValueError('shape mismatch: coords %r, scores %r, orig_hw %r' % (tuple(boxes.shape), tuple(scores.shape), tuple(hw.shape)))
+    out = torch.empty((B, R, 4), dtype=torch.float64, device=dev)
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    _lib.check(lib.odbox_restore_boxes(_lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(hw), B, R, int(image_size),
+                                       _lib.ptr(out), _lib.ptr(counts), _lib.stream_ptr()), 'odbox_restore_boxes')
+    return out, counts
+
+
+def results_json(filenames, boxes64, scores_batch, cat_ids_batch, counts):
+    """The list infdet.py:152-188 dumps into results.json, from `restore_detections`' outputs (one
+    device-to-host copy per tensor instead of one `.numpy()` per detection)."""
+    boxes64 = torch.as_tensor(boxes64).cpu().numpy()
+    scores = torch.as_tensor(scores_batch).cpu().numpy()
+    cats = torch.as_tensor(cat_ids_batch).cpu().numpy()
+    counts = torch.as_tensor(counts).cpu().numpy()
+    out = []
+    for b, filename in enumerate(filenames):
+        anns = [{'bbox': [float(v) for v in boxes64[b, r]], 'class_score': float(scores[b, r]),
+                 'category_id': int(cats[b, r])} for r in range(int(counts[b]))]
+        out.append({'filename': filename, 'annotations': anns})
+    return out

@@ -476,3 +476,38 @@ def padded_batch_boxes(examples, max_items):
         out_b[b, :n] = np.asarray(bb, dtype=F32)
         out_l[b, :n] = ll
     return out_b, out_l
+
+
+# ----------------------------------------------------------------------------------------
+# output side of inference: detections back to original image pixels (infdet.py)
+# ----------------------------------------------------------------------------------------
+
+def restore_detections(coords, scores, orig_hw, image_size):
+    """infdet.py:134-174, the arithmetic of run_eval's per-detection loop, literally: Python floats
+    (fp64), `break` at the first score <= 0.  coords [B,R,4] f32, scores [B,R], orig_hw [B,2]
+    (imh, imw) ints.  Returns (boxes [B,R,4] f64, zero beyond the count; counts [B])."""
+    coords = _f32(coords)
+    scores = _f32(scores)
+    B, R = scores.shape
+    out = np.zeros((B, R, 4), dtype=np.float64)
+    counts = np.zeros(B, dtype=I32)
+    for b in range(B):
+        imh, imw = int(orig_hw[b][0]), int(orig_hw[b][1])
+        max_side = max(imh, imw)
+        pad_y = (max_side - imh) / 2
+        pad_x = (max_side - imw) / 2
+        square_scale = max_side / image_size
+        n = 0
+        for coord, score in zip(coords[b], scores[b]):
+            if float(score) <= 0:
+                break
+            scaled_bb = coord.astype(float) * square_scale
+            xmin, ymin, xmax, ymax = scaled_bb
+            xmin -= pad_x
+            xmax -= pad_x
+            ymin -= pad_y
+            ymax -= pad_y
+            out[b, n] = [xmin, ymin, xmax, ymax]
+            n += 1
+        counts[b] = n
+    return out, counts

@@ -254,3 +254,17 @@ def test_gt_preparation_known_answers():
     assert O.polygon2bbox(poly, want_wh=True).tolist() == [[2, 1, 5, 8]]
     h, _ = O.prepare_example_boxes([[10, 20, 30, 40]], [1], (300, 400), 512, 4, np.float16)
     assert h.dtype == np.float16 and h.tolist() == [[12.796875, 89.625, 51.1875, 140.75]]
+
+
+def test_restore_detections_known_answers():
+    """infdet.py:140-174 by hand: a 480x640 image seen as a 512 square has max_side 640, pad_y 80,
+    pad_x 0, scale 1.25; a 300x200 one has max_side 300, pad_x 50, scale 300/512."""
+    from oracle import odbox_oracle as O
+    coords = np.array([[[64, 128, 256, 384], [0, 0, 512, 512]], [[100, 100, 200, 200], [1, 2, 3, 4]]], np.float32)
+    scores = np.array([[0.9, 0.5], [0.7, 0.0]], np.float32)
+    out, cnt = O.restore_detections(coords, scores, [(480, 640), (300, 200)], 512)
+    assert list(cnt) == [2, 1]
+    np.testing.assert_array_equal(out[0], [[80.0, 80.0, 320.0, 400.0], [0.0, -80.0, 640.0, 560.0]])
+    s = 300 / 512
+    np.testing.assert_array_equal(out[1, 0], [100 * s - 50, 100 * s, 200 * s - 50, 200 * s])
+    np.testing.assert_array_equal(out[1, 1], [0, 0, 0, 0])
