@@ -137,6 +137,15 @@ struct VecLoad<4> {
     }
 };
 
+// The kernels carry a `dbg` word whose bits switch parts of them off for timing experiments
+// (tools/exp_*.sh).  Only a build with ODBOX_TUNING_HOOKS honours it; in the product build the word is
+// forced to 0 at the top of each kernel, so those branches are dead code and cannot be reached.
+#ifdef ODBOX_TUNING_HOOKS
+#define ODBOX_NO_EXPERIMENTS(word) ((void)0)
+#else
+#define ODBOX_NO_EXPERIMENTS(word) ((word) = 0u)
+#endif
+
 constexpr uint32_t SCAN_QUEUES = 64;       // ticket counters (tile queues)
 constexpr uint32_t SCAN_TICKET_STRIDE = 64;   // ints between counters: atomics on one cache line serialise
 constexpr uint32_t SCAN_MAX_ROWS = 512;    // rows per tile; also the size of the pending-key list
@@ -147,6 +156,7 @@ __global__ __launch_bounds__(WAVE) void score_scan_kernel(
     uint32_t total_tiles, int *__restrict__ tile_ticket, int *__restrict__ cand_count,
     uint64_t *__restrict__ cand_keys, uint32_t cand_stride, uint32_t nq_arg, uint32_t dbg)
 {
+    ODBOX_NO_EXPERIMENTS(dbg);
     extern __shared__ __attribute__((aligned(16))) float s_buf[];     // 2 tile buffers, then the pending keys
     constexpr uint32_t LPR = 1u << LL;                  // lanes per row
     constexpr uint32_t G = WAVE >> LL;                  // rows per wave-step
@@ -677,6 +687,7 @@ __device__ __forceinline__ void nms_wave_segment(
     int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys, uint32_t fin_stride,
     uint32_t total_segments, int waves_per_block, uint32_t per_wave_bytes, uint32_t sort_cap, bool coop_on, uint32_t dbg)
 {
+    ODBOX_NO_EXPERIMENTS(dbg);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t seg_id = block * (uint32_t)waves_per_block + wave;
@@ -1033,6 +1044,7 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
     uint32_t total_segments, int waves_per_block, uint32_t per_wave_bytes, uint32_t sort_cap, uint32_t dbg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    ODBOX_NO_EXPERIMENTS(dbg);
     if ((dbg & 4u) && blockIdx.x < coop_blocks) return;       // timing experiments: one path only
     if ((dbg & 8u) && blockIdx.x >= coop_blocks) return;
     if (blockIdx.x < coop_blocks)
