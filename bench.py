@@ -200,7 +200,7 @@ def main():
 
         def bwd_step():
             _lib.check(lib.odbox_match_loss_backward(*common, pb.data_ptr(), ps.data_ptr(), 1.5, 0.25, 1.0,
-                                                     scale2.data_ptr(), gb.data_ptr(), gs.data_ptr(), stream), 'backward')
+                                                     scale2[0:1].data_ptr(), scale2[1:2].data_ptr(), out4[2:3].data_ptr(), gb.data_ptr(), gs.data_ptr(), stream), 'backward')
 
         def fwd16_step():
             _lib.check(lib.odbox_match_loss_f16(*common, hb.data_ptr(), hs.data_ptr(), 1.5, 0.25, 1.0, out4.data_ptr(),
@@ -208,7 +208,7 @@ def main():
 
         def bwd16_step():
             _lib.check(lib.odbox_match_loss_backward_f16(*common, hb.data_ptr(), hs.data_ptr(), 1.5, 0.25, 1.0,
-                                                         scale2.data_ptr(), ghb.data_ptr(), ghs.data_ptr(), stream),
+                                                         scale2[0:1].data_ptr(), scale2[1:2].data_ptr(), out4[2:3].data_ptr(), ghb.data_ptr(), ghs.data_ptr(), stream),
                        'backward_f16')
         fixed = B * (N * 16 + 20 * G)                                          # anchors + ground truth, always fp32
         for name, fn, byt in (('backward', bwd_step, fixed + 2 * B * N * (16 + 4 * C)),

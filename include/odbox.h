@@ -83,25 +83,30 @@ int odbox_match_loss(const float *anchors /*[N,4]*/, const float *gt_boxes /*[B,
                      void *workspace, size_t workspace_bytes, void *stream);
 
 /* The backward pass of the same losses for autograd-style callers (what tf.GradientTape does to
- * metric.py:97-123 in train.py): grad_boxes = grad_scale[0] * d dist_sum / d pred_boxes,
- * grad_scores = grad_scale[1] * d class_sum / d pred_scores.  grad_scale is two floats in DEVICE
- * memory -- typically upstream_gradient / npos, computed on the device from out_loss[2] -- so the
- * normaliser never visits the host and the [B,N,C] gradient is written once, already final.  The
- * match is recomputed from the same inputs (cheaper than saving it: the kernel is bound by the
- * score stream).  No workspace; same alignment rules as odbox_match_loss. */
+ * metric.py:97-123 in train.py):
+ *   grad_boxes  = (*upstream_dist  / n) * d dist_sum  / d pred_boxes
+ *   grad_scores = (*upstream_class / n) * d class_sum / d pred_scores,   n = *normalizer, or 1 if it is 0
+ * All three scalars live in DEVICE memory and are read by the kernel: pass out_loss + 2 of the
+ * forward call as normalizer and the upstream gradients as autograd hands them over, so nothing
+ * visits the host and the [B,N,C] gradient is written once, already final.  A NULL upstream means
+ * that loss is unused (its gradient is written as zeros); a NULL normalizer means 1.  The match is
+ * recomputed from the same inputs (cheaper than saving it: the kernel is bound by the score
+ * stream).  No workspace; same alignment rules as odbox_match_loss. */
 int odbox_match_loss_backward(const float *anchors /*[N,4]*/, const float *gt_boxes /*[B,G,4]*/,
                               const int32_t *gt_labels /*[B,G]*/, int B, int N, int G, int C,
                               float img_h, float img_w, float neg_thr, float pos_thr,
                               const float *pred_boxes /*[B,N,4]*/, const float *pred_scores /*[B,N,C]*/,
                               float gamma, float alpha, float huber_delta,
-                              const float *grad_scale /*device [2]*/, float *grad_boxes /*[B,N,4]*/,
-                              float *grad_scores /*[B,N,C]*/, void *stream);
+                              const float *upstream_dist /*device scalar or NULL*/,
+                              const float *upstream_class /*device scalar or NULL*/,
+                              const float *normalizer /*device scalar or NULL*/,
+                              float *grad_boxes /*[B,N,4]*/, float *grad_scores /*[B,N,C]*/, void *stream);
 
 /* The same two entry points for fp16 predictions: the reference's --use_fp16 run (detection.py:
  * 296-300, mixed_float16) hands fp16 model outputs to metric.py, which casts them to fp32 before
  * any arithmetic (metric.py:16-17; Keras' Huber does the same).  Here the four prediction /
  * gradient tensors are IEEE binary16 in memory: widened on load (exact), all arithmetic in fp32,
- * gradients rounded to nearest even on store; out_loss and grad_scale stay fp32.  Half the bytes
+ * gradients rounded to nearest even on store; out_loss, upstream and normalizer stay fp32.  Half the bytes
  * of the dominant stream.  pred_boxes / grad_boxes 8-byte aligned, scores 2-byte aligned with
  * grad_scores on the 16-byte phase of pred_scores. */
 int odbox_match_loss_f16(const float *anchors, const float *gt_boxes, const int32_t *gt_labels,
@@ -115,8 +120,9 @@ int odbox_match_loss_backward_f16(const float *anchors, const float *gt_boxes, c
                                   int B, int N, int G, int C, float img_h, float img_w, float neg_thr,
                                   float pos_thr, const void *pred_boxes, const void *pred_scores,
                                   float gamma, float alpha, float huber_delta,
-                                  const float *grad_scale /*device [2], fp32*/, void *grad_boxes,
-                                  void *grad_scores, void *stream);
+                                  const float *upstream_dist, const float *upstream_class,
+                                  const float *normalizer /*three fp32 device scalars, each may be NULL*/,
+                                  void *grad_boxes, void *grad_scores, void *stream);
 
 /* metric.py:9-38 focal_loss(y_true, y_pred, gamma, alpha, from_logits=False, reduction='sum') on
  * dense targets (y_true == 1 marks the positive class): out[1] = sum over all n elements

@@ -415,6 +415,12 @@ __device__ __forceinline__ float focal_neg(float pred, const LossParams lp, floa
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v4h __attribute__((ext_vector_type(4)));
 
+// Device-resident factors of the backward entry point (see match_loss_kernel).
+struct GradScale {
+    const float *up_dist, *up_class, *normalizer;
+    int scaled;
+};
+
 template <typename T> struct PredIO;
 template <> struct PredIO<float> {
     static constexpr uint32_t VEC = 4;
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     const float4 *__restrict__ anchors, const float4 *__restrict__ gt_boxes,
     const int32_t *__restrict__ gt_labels, int N, int G, int C, float img_h, float img_w,
     float neg_thr, float pos_thr, const typename PredIO<T>::box_t *__restrict__ pred_boxes,
-    const T *__restrict__ pred_scores, LossParams lp, const float *__restrict__ grad_scale,
+    const T *__restrict__ pred_scores, LossParams lp, GradScale gsc,
     typename PredIO<T>::box_t *__restrict__ grad_boxes, T *__restrict__ grad_scores, float *__restrict__ partials,
     uint32_t tiles_per_image, uint32_t c_magic)
 {
@@ -470,12 +476,15 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     __shared__ float s_red[4][ME_TILE / WAVE];
     __shared__ unsigned long long s_top[ME_TILE];   // per foreground anchor: (ordered top score, ~class), LDS atomic max
 
-    // backward entry point: gradients times two device-resident factors (box, score) -- the
-    // 1 / npos normaliser and the upstream gradient folded in, so no second pass over [B,N,C]
+    // backward entry point: gradients times upstream / normaliser, all three read from device
+    // memory here (NULL upstream = that loss is unused: zeros; NULL or zero normaliser = 1, like
+    // metric.py:121), so no second pass over [B,N,C] and no host round trip for npos
     float gs_box = 1.0f, gs_cls = 1.0f;
-    if (GRADS && grad_scale) {
-        gs_box = grad_scale[0];
-        gs_cls = grad_scale[1];
+    if (GRADS && gsc.scaled) {
+        float nrm = gsc.normalizer ? *gsc.normalizer : 1.0f;
+        nrm = nrm != 0.0f ? nrm : 1.0f;
+        gs_box = (gsc.up_dist ? *gsc.up_dist : 0.0f) / nrm;
+        gs_cls = (gsc.up_class ? *gsc.up_class : 0.0f) / nrm;
     }
 
     const uint32_t tid = threadIdx.x;
@@ -858,14 +867,14 @@ size_t odbox_match_loss_workspace(int B, int N)
 }
 
 // Shared by odbox_match_loss (out_loss + optional unscaled gradients) and odbox_match_loss_backward
-// (gradients only, times grad_scale[2] read on the device).
+// (gradients only, times upstream / normaliser read on the device).
 // T = element type of the four prediction / gradient tensors (float or _Float16).
 extern "C++" {
 template <typename T>
 static int match_loss_run(const char *name, const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B,
                           int N, int G, int C, float img_h, float img_w, float neg_thr, float pos_thr,
                           const T *pred_boxes, const T *pred_scores, float gamma, float alpha, float huber_delta,
-                          float *out_loss, const float *grad_scale, T *grad_boxes, T *grad_scores,
+                          float *out_loss, GradScale gsc, T *grad_boxes, T *grad_scores,
                           void *workspace, size_t workspace_bytes, void *stream)
 {
     typedef typename PredIO<T>::box_t box_t;
@@ -881,7 +890,8 @@ static int match_loss_run(const char *name, const float *anchors, const float *g
                     sizeof(box_t));
     if (((uintptr_t)pred_scores & el_mask) || (grad_scores && ((uintptr_t)pred_scores & 15u) != ((uintptr_t)grad_scores & 15u)))
         return fail(ODBOX_EINVAL, "%s: grad_scores must have the 16-byte phase of pred_scores", name);
-    if (grad_scale && ((uintptr_t)grad_scale & 3u)) return fail(ODBOX_EINVAL, "%s: grad_scale must be 4-byte aligned", name);
+    if ((((uintptr_t)gsc.up_dist | (uintptr_t)gsc.up_class | (uintptr_t)gsc.normalizer) & 3u))
+        return fail(ODBOX_EINVAL, "%s: upstream / normalizer scalars must be 4-byte aligned", name);
     if (out_loss) {
         const size_t need = odbox_match_loss_workspace(B, N);
         if (!workspace || workspace_bytes < need)
@@ -901,7 +911,7 @@ static int match_loss_run(const char *name, const float *anchors, const float *g
     auto launch = [&](auto kernel, box_t *gb, T *gs) {
         hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(ME_TILE), 0, st, (const float4 *)anchors,
                            (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w, neg_thr, pos_thr,
-                           (const box_t *)pred_boxes, pred_scores, lp, grad_scale, gb, gs, partials, (uint32_t)tiles,
+                           (const box_t *)pred_boxes, pred_scores, lp, gsc, gb, gs, partials, (uint32_t)tiles,
                            magic);
     };
     auto pick = [&](auto grads, box_t *gb, T *gs) {
@@ -925,19 +935,20 @@ int odbox_match_loss(const float *anchors, const float *gt_boxes, const int32_t 
 {
     if (!out_loss) return fail(ODBOX_EINVAL, "odbox_match_loss: NULL pointer");
     return match_loss_run<float>("odbox_match_loss", anchors, gt_boxes, gt_labels, B, N, G, C, img_h, img_w, neg_thr, pos_thr,
-                          pred_boxes, pred_scores, gamma, alpha, huber_delta, out_loss, nullptr, grad_boxes, grad_scores,
-                          workspace, workspace_bytes, stream);
+                          pred_boxes, pred_scores, gamma, alpha, huber_delta, out_loss, GradScale{nullptr, nullptr, nullptr, 0},
+                          grad_boxes, grad_scores, workspace, workspace_bytes, stream);
 }
 
 int odbox_match_loss_backward(const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B, int N, int G,
                               int C, float img_h, float img_w, float neg_thr, float pos_thr, const float *pred_boxes,
                               const float *pred_scores, float gamma, float alpha, float huber_delta,
-                              const float *grad_scale, float *grad_boxes, float *grad_scores, void *stream)
+                              const float *upstream_dist, const float *upstream_class, const float *normalizer,
+                              float *grad_boxes, float *grad_scores, void *stream)
 {
-    if (!grad_scale || !grad_boxes || !grad_scores) return fail(ODBOX_EINVAL, "odbox_match_loss_backward: NULL pointer");
+    if (!grad_boxes || !grad_scores) return fail(ODBOX_EINVAL, "odbox_match_loss_backward: NULL pointer");
     return match_loss_run<float>("odbox_match_loss_backward", anchors, gt_boxes, gt_labels, B, N, G, C, img_h, img_w, neg_thr,
-                          pos_thr, pred_boxes, pred_scores, gamma, alpha, huber_delta, nullptr, grad_scale, grad_boxes,
-                          grad_scores, nullptr, 0, stream);
+                          pos_thr, pred_boxes, pred_scores, gamma, alpha, huber_delta, nullptr,
+                          GradScale{upstream_dist, upstream_class, normalizer, 1}, grad_boxes, grad_scores, nullptr, 0, stream);
 }
 
 int odbox_match_loss_f16(const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B, int N, int G,
@@ -948,21 +959,21 @@ int odbox_match_loss_f16(const float *anchors, const float *gt_boxes, const int3
     if (!out_loss) return fail(ODBOX_EINVAL, "odbox_match_loss_f16: NULL pointer");
     return match_loss_run<_Float16>("odbox_match_loss_f16", anchors, gt_boxes, gt_labels, B, N, G, C, img_h, img_w, neg_thr,
                                     pos_thr, (const _Float16 *)pred_boxes, (const _Float16 *)pred_scores, gamma, alpha,
-                                    huber_delta, out_loss, nullptr, (_Float16 *)grad_boxes, (_Float16 *)grad_scores,
-                                    workspace, workspace_bytes, stream);
+                                    huber_delta, out_loss, GradScale{nullptr, nullptr, nullptr, 0}, (_Float16 *)grad_boxes,
+                                    (_Float16 *)grad_scores, workspace, workspace_bytes, stream);
 }
 
 int odbox_match_loss_backward_f16(const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B, int N,
                                   int G, int C, float img_h, float img_w, float neg_thr, float pos_thr,
                                   const void *pred_boxes, const void *pred_scores, float gamma, float alpha,
-                                  float huber_delta, const float *grad_scale, void *grad_boxes, void *grad_scores,
-                                  void *stream)
+                                  float huber_delta, const float *upstream_dist, const float *upstream_class,
+                                  const float *normalizer, void *grad_boxes, void *grad_scores, void *stream)
 {
-    if (!grad_scale || !grad_boxes || !grad_scores) return fail(ODBOX_EINVAL, "odbox_match_loss_backward_f16: NULL pointer");
+    if (!grad_boxes || !grad_scores) return fail(ODBOX_EINVAL, "odbox_match_loss_backward_f16: NULL pointer");
     return match_loss_run<_Float16>("odbox_match_loss_backward_f16", anchors, gt_boxes, gt_labels, B, N, G, C, img_h, img_w,
                                     neg_thr, pos_thr, (const _Float16 *)pred_boxes, (const _Float16 *)pred_scores, gamma,
-                                    alpha, huber_delta, nullptr, grad_scale, (_Float16 *)grad_boxes,
-                                    (_Float16 *)grad_scores, nullptr, 0, stream);
+                                    alpha, huber_delta, nullptr, GradScale{upstream_dist, upstream_class, normalizer, 1},
+                                    (_Float16 *)grad_boxes, (_Float16 *)grad_scores, nullptr, 0, stream);
 }
 
 size_t odbox_focal_loss_workspace(size_t n)

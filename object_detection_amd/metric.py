@@ -125,20 +125,31 @@ class _DetectionLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_dist, g_cls, _g_npos, _g_hits):
-        lib = _lib.load()
         pb, ps, anchors, gt, lab, out = ctx.saved_tensors
-        B, N, G, C, neg, pos, gamma, alpha, delta = ctx.cfg
-        zero = out.new_zeros(())
-        up = torch.stack([zero if g_dist is None else g_dist.to(torch.float32),
-                          zero if g_cls is None else g_cls.to(torch.float32)])
-        scale = (up / torch.where(out[2] != 0, out[2], torch.ones_like(out[2]))).contiguous()
-        gb = torch.empty_like(pb)
-        gs = torch.empty_like(ps)
-        _lib.check(_entry(lib, 'odbox_match_loss_backward', pb.dtype)(
-            *_loss_args(lib, anchors, ctx.image_hw, gt, lab, B, N, G, C, neg, pos, pb, ps),
-            float(gamma), float(alpha), float(delta), _lib.ptr(scale), _lib.ptr(gb), _lib.ptr(gs),
-            _lib.stream_ptr()), 'odbox_match_loss_backward')
+        gb, gs = _backward_launch(ctx.cfg, ctx.image_hw, anchors, gt, lab, pb, ps, g_dist, g_cls, out[2:3])
         return gb, gs, None, None, None, None, None
+
+
+def _scalar(t, dev):
+    """An upstream gradient as a 4-byte-aligned fp32 device scalar (None stays None = unused loss)."""
+    if t is None:
+        return None
+    return t.detach().to(device=dev, dtype=torch.float32).reshape(1).contiguous()
+
+
+def _backward_launch(cfg, image_hw, anchors, gt, lab, pb, ps, up_dist, up_class, normalizer):
+    """One `odbox_match_loss_backward` launch: the upstream gradients and the normaliser stay on the
+    device, the kernel folds them in; returns (grad_boxes, grad_scores) in the predictions' dtype."""
+    lib = _lib.load()
+    B, N, G, C, neg, pos, gamma, alpha, delta = cfg
+    up_dist, up_class = _scalar(up_dist, pb.device), _scalar(up_class, pb.device)
+    gb = torch.empty_like(pb)
+    gs = torch.empty_like(ps)
+    _lib.check(_entry(lib, 'odbox_match_loss_backward', pb.dtype)(
+        *_loss_args(lib, anchors, image_hw, gt, lab, B, N, G, C, neg, pos, pb, ps),
+        float(gamma), float(alpha), float(delta), _lib.ptr(up_dist), _lib.ptr(up_class), _lib.ptr(normalizer),
+        _lib.ptr(gb), _lib.ptr(gs), _lib.stream_ptr()), 'odbox_match_loss_backward')
+    return gb, gs
 
 
 def detection_loss(anchors, image_hw, true_bboxes, true_labels, pred_bboxes, pred_scores, num_classes,
@@ -150,11 +161,12 @@ def detection_loss(anchors, image_hw, true_bboxes, true_labels, pred_bboxes, pre
 
     When pred_bboxes / pred_scores require grad (and grad mode is on) the two losses are
     differentiable: `.backward()` runs `odbox_match_loss_backward`.  return_grads=True instead
-    returns (grad_boxes [B,N,4], grad_scores [B,N,C]) explicitly, in one launch with the losses:
-    the gradients of the two RETURNED losses w.r.t. pred_bboxes / pred_scores.
+    returns (grad_boxes [B,N,4], grad_scores [B,N,C]) explicitly: the gradients of the two
+    RETURNED losses w.r.t. pred_bboxes / pred_scores (a forward launch and a backward launch that
+    reads the normaliser on the device -- cheaper than scaling unnormalised gradients afterwards).
 
     float16 predictions are read as they are (widened to fp32 in registers like metric.py:16-17);
-    their autograd gradients come back in float16, the explicit ones in float32.
+    their gradients come back in float16.
 
     return_hits=True appends the number of foreground anchors whose top predicted class is the
     matched class (hits / normalizer = the CategoricalAccuracy of metric.py:128-130)."""
@@ -177,24 +189,16 @@ def detection_loss(anchors, image_hw, true_bboxes, true_labels, pred_bboxes, pre
         return res if return_hits else res[:3]
     pb, ps = pb.detach(), ps.detach()
     out = torch.empty(4, dtype=torch.float32, device=dev)
-    gb = gs = None
-    if return_grads:
-        gb = torch.empty_like(pb)
-        gs = torch.empty_like(ps)
     ws = _workspace(dev, lib.odbox_match_loss_workspace(B, N))
     _lib.check(_entry(lib, 'odbox_match_loss', pdt)(
         *_loss_args(lib, anchors, image_hw, gt, lab, B, N, G, C, negative_overlap, positive_overlap, pb, ps),
-        float(gamma), float(alpha), float(huber_delta), _lib.ptr(out), _lib.ptr(gb), _lib.ptr(gs),
+        float(gamma), float(alpha), float(huber_delta), _lib.ptr(out), None, None,
         _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), 'odbox_match_loss')
+    res = (out[0], out[1], out[2])
     if return_grads:
-        # the kernel returns gradients of the unnormalised sums; scale on the device, no sync
-        inv = torch.where(out[2] != 0, 1.0 / out[2], torch.ones_like(out[2]))
-        if pdt == torch.float16:      # unnormalised sums are what fits fp16 best: scale in fp32
-            res = (out[0], out[1], out[2], gb.float().mul_(inv), gs.float().mul_(inv))
-        else:
-            res = (out[0], out[1], out[2], gb.mul_(inv), gs.mul_(inv))
-    else:
-        res = (out[0], out[1], out[2])
+        cfg = (B, N, G, C, negative_overlap, positive_overlap, gamma, alpha, huber_delta)
+        one = torch.ones(1, dtype=torch.float32, device=dev)
+        res = res + _backward_launch(cfg, image_hw, anchors, gt, lab, pb, ps, one, one, out[2:3])
     return res + (out[3],) if return_hits else res
 
 

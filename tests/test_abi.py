@@ -159,12 +159,12 @@ def test_every_entry_rejects_bad_arguments_without_touching_the_gpu(lib):
         ('odbox_match_encode', (p, p, None, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, None, None, None, None), -1),   # labels needed
         ('odbox_match_loss', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, p, p, None, p, 1 << 20, None), -1),   # one gradient only
         ('odbox_match_loss', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, p, None, None, p, 4, None), -3),        # workspace
-        ('odbox_match_loss_backward', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, None, p, p, None), -1),        # no scale
-        ('odbox_match_loss_backward', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, p, odd, p, None), -1),         # alignment
-        ('odbox_match_loss_backward', (p, p, p, 1, 4, 2, 0, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, p, p, p, None), -1),           # C < 1
+        ('odbox_match_loss_backward', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, p, p, p, None, p, None), -1),    # no grad_boxes
+        ('odbox_match_loss_backward', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, p, p, p, odd, p, None), -1),     # alignment
+        ('odbox_match_loss_backward', (p, p, p, 1, 4, 2, 0, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, None, None, None, p, p, None), -1),  # C < 1
         ('odbox_match_loss_f16', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, odd, p, 1.5, 0.25, 1.0, p, None, None, p, 1 << 20, None), -1),   # boxes 8-byte aligned
         ('odbox_match_loss_f16', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, None, None, None, p, 1 << 20, None), -1),  # no out_loss
-        ('odbox_match_loss_backward_f16', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, p, p, None, None), -1),
+        ('odbox_match_loss_backward_f16', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, p, p, p, p, None, None), -1),
         ('odbox_focal_loss', (p, p, 16, 1.5, 0.25, None, None, p, 1 << 20, None), -1),
         ('odbox_focal_loss', (p, p, 16, 1.5, 0.25, p, None, p, 1, None), -3),
         ('odbox_bbox_overlap', (None, p, 1, 4, 2, 0, p, None), -1),

@@ -222,10 +222,11 @@ def test_fp16_predictions_losses_and_gradients(C, offset):
     np.testing.assert_allclose(tpb.grad.float().cpu().numpy(), 1024.0 * rgb / rn, rtol=H_RTOL, atol=H_ATOL)
     np.testing.assert_allclose(tps.grad.float().cpu().numpy(), 512.0 * rgs / rn, rtol=H_RTOL, atol=H_ATOL)
     assert torch.isfinite(tps.grad).all()
-    # explicit gradients from the forward launch
+    # explicit gradients (forward launch + backward launch with upstream 1)
     _, _, _, gb, gs = M.detection_loss(anchors, hw, gt, lab, hpb, hps, C, return_grads=True)
-    np.testing.assert_allclose(gb.cpu().numpy() * rn, rgb, rtol=H_RTOL, atol=H_ATOL)
-    np.testing.assert_allclose(gs.cpu().numpy() * rn, rgs, rtol=H_RTOL, atol=H_ATOL)
+    assert gb.dtype == torch.float16 and gs.dtype == torch.float16
+    np.testing.assert_allclose(gb.float().cpu().numpy(), rgb / rn, rtol=H_RTOL, atol=H_ATOL)
+    np.testing.assert_allclose(gs.float().cpu().numpy(), rgs / rn, rtol=H_RTOL, atol=H_ATOL)
     # nothing outside the view was written
     assert (flat[:offset] == 0).all() and (flat[offset + ps.size:] == 0).all()
 

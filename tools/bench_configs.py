@@ -113,7 +113,7 @@ def main():
         def step_bwd():
             rc = lib.odbox_match_loss_backward(anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C, float(c['S']),
                                                float(c['S']), 0.4, 0.5, pb.data_ptr(), ps.data_ptr(), 1.5, 0.25, 1.0,
-                                               scale.data_ptr(), gb.data_ptr(), gs.data_ptr(), st)
+                                               scale[0:1].data_ptr(), scale[1:2].data_ptr(), out[2:3].data_ptr(), gb.data_ptr(), gs.data_ptr(), st)
             assert rc == 0
         t = event_time(step_bwd, args.iters)
         byts = B * (N * (32 + 4 * C) + 20 * G) * 2
@@ -132,13 +132,25 @@ def main():
         def step_h_bwd():
             rc = lib.odbox_match_loss_backward_f16(anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C,
                                                    float(c['S']), float(c['S']), 0.4, 0.5, hb.data_ptr(), hs.data_ptr(),
-                                                   1.5, 0.25, 1.0, scale.data_ptr(), ghb.data_ptr(), ghs.data_ptr(), st)
+                                                   1.5, 0.25, 1.0, scale[0:1].data_ptr(), scale[1:2].data_ptr(), out[2:3].data_ptr(), ghb.data_ptr(), ghs.data_ptr(), st)
             assert rc == 0
         for name, fn, mult in (('2_loss_fwd_f16', step_h_fwd, 1), ('2_loss_backward_f16', step_h_bwd, 2)):
             t = event_time(fn, args.iters)
             byts = B * (N * 16 + mult * N * (8 + 2 * C) + 20 * G)
             rows.append(dict(cfg=name, B=B, N=N, G=G, C=C, us=t * 1e6, img_s=B / t, GBs=byts / t / 1e9,
                              frac_hbm=byts / t / 1e9 / HBM))
+        # what a training step pays through the Python mirror: forward, then autograd backward of
+        # dist + class (two HIP launches + loss_reduce; everything else is host-side bookkeeping)
+        from object_detection_amd import metric as M
+        tpb, tps = pb.clone().requires_grad_(True), ps.clone().requires_grad_(True)
+
+        def step_autograd():
+            tpb.grad = None
+            tps.grad = None
+            d, cl, _ = M.detection_loss(anchors, (c['S'], c['S']), gt, lab, tpb, tps, C)
+            (d + cl).backward()
+        t = event_time(step_autograd, args.iters)
+        rows.append(dict(cfg='2_loss_autograd_step', B=B, N=N, G=G, C=C, us=t * 1e6, img_s=B / t))
     # COCO matching of the gathered detections of one cfg-5 eval batch (512 images)
     if 6 in args.cfg:
         import ctypes
