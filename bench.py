@@ -95,6 +95,26 @@ def cpu_baseline_match(anchors_np, gt, lab, C, S, budget_s=6.0):
     return out
 
 
+def cpu_baseline_nms(anchors_np, reg_np, sc_np, S, budget_s=4.0):
+    """The oracle's C decode + NMS on a bounded sample of the same cfg-5 batch (16 images per pass,
+    repeated for about `budget_s` seconds per thread setting)."""
+    from oracle import c_oracle
+    out = {}
+    n_img = min(16, reg_np.shape[0])
+    reg_np, sc_np = reg_np[:n_img], sc_np[:n_img]
+    for name, threads in (('multi', min(16, os.cpu_count() or 1)), ('single', 1)):
+        c_oracle.decode_nms(anchors_np, reg_np[:2], sc_np[:2], (S, S), threads=threads)       # warm
+        n, t0 = 0, time.perf_counter()
+        while True:
+            c_oracle.decode_nms(anchors_np, reg_np, sc_np, (S, S), threads=threads)
+            n += n_img
+            el = time.perf_counter() - t0
+            if el > budget_s:
+                break
+        out[name] = (n / el, threads, n)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -233,6 +253,9 @@ def main():
                                                p3p4_anchors=9 * (64 * 64 + 32 * 32))
         reg5 = torch.as_tensor(reg5_np).to(dev)
         sc5 = torch.as_tensor(sc5_np).to(dev)
+        cb5 = None
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            cb5 = cpu_baseline_nms(anchors5.cpu().numpy(), reg5_np, sc5_np, S5)
         del reg5_np, sc5_np
         out = {}
 
@@ -255,6 +278,12 @@ def main():
                          'traffic': load_traffic('score_scan_kernel')},
             'detections_per_image_mean': float((out['det'][1] > 0).sum().item()) / (world * B5),
         }
+        if cb5 is not None:
+            result['decode_nms']['cpu_baseline'] = {
+                'value': round(cb5['multi'][0], 1), 'unit': 'images/s', 'cores': cb5['multi'][1], 'kind': 'port',
+                'sample': 'oracle/odbox_oracle.c decode + per-class NMS + top-k on the first 16 images of the same '
+                          'batch, repeated to %d images, OpenMP over images' % cb5['multi'][2],
+                'value_1core': round(cb5['single'][0], 1)}
 
     # ---------------- CPU baseline (rank 0, N = 1 only) ------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
