@@ -91,11 +91,15 @@ struct TileMatch {
     bool live;         // n < N
 };
 
-template <int TILE>
+// `early` is called once by every thread after the block's first global loads (anchor, first GT
+// chunk) have been consumed and before any of the matching arithmetic: work issued there (the
+// dense zero stream of match_encode_kernel) drains while the VALUs do the match.
+template <int TILE, typename EarlyWork>
 __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ anchors,
                                                 const float4 *__restrict__ gt_boxes,
                                                 const int32_t *__restrict__ gt_labels, uint32_t b, uint32_t n0, int N,
-                                                int G, int C, float img_h, float img_w, float neg_thr, float pos_thr)
+                                                int G, int C, float img_h, float img_w, float neg_thr, float pos_thr,
+                                                EarlyWork early)
 {
     __shared__ float4 s_gt[ME_GCHUNK];
     __shared__ float2 s_ga[ME_GCHUNK];          // (area, 1.0 if padded row else 0.0)
@@ -115,15 +119,7 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
     float wx0 = live ? a.x : INFINITY, wy0 = live ? a.y : INFINITY;
     float wx1 = live ? a.z : -INFINITY, wy1 = live ? a.w : -INFINITY;
     float wmin_area = live ? a_area : INFINITY;
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) {
-        wx0 = fminf(wx0, __shfl_xor(wx0, off));
-        wy0 = fminf(wy0, __shfl_xor(wy0, off));
-        wx1 = fmaxf(wx1, __shfl_xor(wx1, off));
-        wy1 = fmaxf(wy1, __shfl_xor(wy1, off));
-        wmin_area = fminf(wmin_area, __shfl_xor(wmin_area, off));
-    }
-    const bool can_skip_zero = wmin_area >= 0.0f;      // false also for NaN
+    bool can_skip_zero = false;
 
     // ---- phase 1: argmax_g IoU ------------------------------------------------------------
     int best = 0;
@@ -139,6 +135,20 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
             float gmax = fmaxf(fmaxf(gb.x, gb.y), fmaxf(gb.z, gb.w));    // bndbox.py:295
             s_gt[g] = gb;
             s_ga[g] = make_float2(area, gmax < 0.0f ? 1.0f : 0.0f);
+        }
+        if (g0 == 0) {
+            // every global load issued so far has been consumed: from here to the label / box gathers
+            // at the end the match is VALU and LDS work only, so memory work issued now overlaps it
+            early();
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) {
+                wx0 = fminf(wx0, __shfl_xor(wx0, off));
+                wy0 = fminf(wy0, __shfl_xor(wy0, off));
+                wx1 = fmaxf(wx1, __shfl_xor(wx1, off));
+                wy1 = fmaxf(wy1, __shfl_xor(wy1, off));
+                wmin_area = fminf(wmin_area, __shfl_xor(wmin_area, off));
+            }
+            can_skip_zero = wmin_area >= 0.0f;         // false also for NaN
         }
         __syncthreads();
         // this wave's work list: 64 GT rows per step, one per lane, order preserved
@@ -203,11 +213,10 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
     return r;
 }
 
-// STREAM: the dense labels leave through cache-bypassing stores.  Measured: outputs that fit the
-// 256 MB Infinity Cache (cfg 2: 234 MB) are 1.5x FASTER with plain stores (40 vs 63 us), outputs
-// far beyond it (cfg 3: 2.2 GB per GPU) 6 % faster bypassing it (364 vs 387 us; `sc1 nt`, plain `nt` 372).
-// The streaming variant also runs 128-anchor tiles (364 -> 360 us on cfg 3); the small launches
-// prefer 256 (cfg 2: 40 us vs 45 us with 128, 41 us with 512).
+// STREAM: the dense labels leave through cache-bypassing (nontemporal) stores.  Measured: outputs
+// that fit the 256 MB Infinity Cache (cfg 2: 234 MB) are 1.5x FASTER with plain stores, outputs far
+// beyond it (cfg 3: 2.2 GB per GPU) 6 % faster bypassing it.  The streaming variant also runs
+// 128-anchor tiles (cfg 3), the small launches prefer 256 (cfg 2: 128 and 512 are both slower).
 template <bool STREAM>
 __global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE) void match_encode_kernel(
     const float4 *__restrict__ anchors, const float4 *__restrict__ gt_boxes,
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE) void match_encod
 {
     constexpr int TILE = STREAM ? ME_TILE_STREAM : ME_TILE;
     __shared__ float s_reg[TILE * 5];
-    __shared__ uint32_t s_ls[TILE];          // (label + 1) | (state + 1) << 16
+    (void)d_magic;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
@@ -228,7 +237,34 @@ __global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE) void match_encod
     const bool live = n < (uint32_t)N;
     const uint32_t tile_n = min((uint32_t)TILE, (uint32_t)N - n0);
 
-    const TileMatch tm = match_tile<TILE>(anchors, gt_boxes, gt_labels, b, n0, N, G, C, img_h, img_w, neg_thr, pos_thr);
+    // ---- phase 3b first: the [tile,C+1] one-hot + state rows are zero except for the state of
+    // not-background anchors and the one 1.0 of foreground anchors.  The zeros do not depend on the
+    // match, so they are streamed (flat 16-byte stores) from inside match_tile, right after its
+    // global loads, and drain while the VALUs do the matching; the few non-zero elements are
+    // patched by their anchor's thread afterwards.  Compiler-visible stores on purpose: the patch
+    // overwrites bytes of this stream, and only stores the compiler knows about are ordered by
+    // the barrier in between (see match_loss_kernel).
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    const uint32_t d = (uint32_t)C + 1u;
+    float *lab_p = out_lab ? out_lab + ((size_t)b * N + n0) * d : nullptr;
+    auto zero_stream = [&] {
+        if (!out_lab) return;
+        const uint32_t count = tile_n * d;
+        const uint32_t head = min(count, (uint32_t)((16u - ((uintptr_t)lab_p & 15u)) & 15u) >> 2);
+        const uint32_t nvec = (count - head) >> 2;
+        if (tid < head) lab_p[tid] = 0.0f;
+        const v4f_ z = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (uint32_t v = tid; v < nvec; v += TILE) {
+            v4f_ *dst = reinterpret_cast<v4f_ *>(lab_p + head + 4 * v);
+            if (STREAM) __builtin_nontemporal_store(z, dst);
+            else *dst = z;
+        }
+        const uint32_t done = head + 4 * nvec;
+        if (tid < count - done) lab_p[done + tid] = 0.0f;
+    };
+
+    const TileMatch tm = match_tile<TILE>(anchors, gt_boxes, gt_labels, b, n0, N, G, C, img_h, img_w, neg_thr, pos_thr,
+                                          zero_stream);
     const float4 a = tm.a;
     const float best_iou = tm.best_iou;
     const int best = tm.best, state = tm.state, label = tm.label;
@@ -249,8 +285,17 @@ __global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE) void match_encod
         s_reg[tid * 5 + 3] = (((g.w - a.w) / ah) - 0.0f) / 0.2f;
         s_reg[tid * 5 + 4] = (float)state;
     }
-    s_ls[tid] = (uint32_t)(label + 1) | ((uint32_t)(state + 1) << 16);
-    __syncthreads();
+    // Every zero store of this thread has reached L2 before any thread of the block patches (the
+    // box gather above already implies it when out_reg is set: vmcnt counts in order).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();            // s_reg complete; the zero stream of the whole tile is in L2
+
+    // ---- phase 3b, second half: the non-zero elements of this thread's own row ----------------
+    if (out_lab && live) {
+        float *rowp = lab_p + (size_t)tid * d;
+        if (state != 0) rowp[d - 1] = (float)state;
+        if (label >= 0) rowp[label] = 1.0f;
+    }
 
     // ---- phase 3a: [tile,5] regression rows, flat 16-byte stores ---------------------------
     if (out_reg) {
@@ -265,58 +310,6 @@ __global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE) void match_encod
         }
         const uint32_t done = head + 4 * nvec;
         if (tid < count - done) p[done + tid] = s_reg[done + tid];
-    }
-
-    // ---- phase 3b: [tile,C+1] one-hot + state rows, flat 16-byte stores --------------------
-    if (out_lab) {
-        const uint32_t d = (uint32_t)C + 1u;
-        float *p = out_lab + ((size_t)b * N + n0) * d;
-        const uint32_t count = tile_n * d;
-        const uint32_t head = min(count, (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) >> 2);
-        const uint32_t nvec = (count - head) >> 2;
-        auto element = [&](uint32_t ls, uint32_t col) -> float {
-            const uint32_t lab1 = ls & 0xffffu;                      // label + 1, 0 = none
-            const float st = (float)((int)(ls >> 16) - 1);
-            return col == d - 1 ? st : (col + 1 == lab1 ? 1.0f : 0.0f);
-        };
-        if (tid < head) {
-            uint32_t q, r;
-            divmod_u32(tid, d, d_magic, q, r);
-            p[tid] = element(s_ls[q], r);
-        }
-        for (uint32_t v = tid; v < nvec; v += TILE) {
-            const uint32_t e = head + 4 * v;
-            uint32_t q, r;
-            divmod_u32(e, d, d_magic, q, r);
-            uint32_t ls = s_ls[q];
-            float o[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                o[k] = element(ls, r);
-                if (++r == d) {
-                    r = 0;
-                    ++q;
-                    ls = s_ls[min(q, (uint32_t)TILE - 1)];
-                }
-            }
-            if (STREAM) {
-                typedef float v4f_ __attribute__((ext_vector_type(4)));
-                const v4f_ ov = {o[0], o[1], o[2], o[3]};
-                asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p + e), "v"(ov) : "memory");
-            } else {
-                // device-scope (sc1) stores: same data path, measured 6 % faster on the small launch of
-                // config 1 (26.2 -> 24.7 us) and level on config 2; sc0 and sc0 sc1 measure no better
-                typedef float v4f_ __attribute__((ext_vector_type(4)));
-                const v4f_ ov = {o[0], o[1], o[2], o[3]};
-                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p + e), "v"(ov) : "memory");
-            }
-        }
-        const uint32_t done = head + 4 * nvec;
-        if (tid < count - done) {
-            uint32_t q, r;
-            divmod_u32(done + tid, d, d_magic, q, r);
-            p[done + tid] = element(s_ls[q], r);
-        }
     }
 }
 
@@ -507,7 +500,8 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     vec_t cur = IO::fill(0.5f);
     if (d >= VEC && nvec) cur = pv4[min(tid, nvec - 1)];
 
-    const TileMatch tm = match_tile<ME_TILE>(anchors, gt_boxes, gt_labels, b, n0, N, G, C, img_h, img_w, neg_thr, pos_thr);
+    const TileMatch tm = match_tile<ME_TILE>(anchors, gt_boxes, gt_labels, b, n0, N, G, C, img_h, img_w, neg_thr, pos_thr,
+                                             [] {});
     s_live[tid] = tm.live && tm.state != -1 ? (tm.state == 1 ? -1.0f : 1.0f) : 0.0f;
     s_top[tid] = 0ull;
     // metric.py:128-130 (CategoricalAccuracy over the foreground anchors) rides on the stream: a
