@@ -37,6 +37,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', 'hipcc')
     # ODBOX_TUNING_HOOKS=1: the library reads the ODBOX_SCAN_* / ODBOX_NMS_DBG experiment knobs (tools/exp_*.sh)
     hooks = ['-DODBOX_TUNING_HOOKS'] if os.environ.get('ODBOX_TUNING_HOOKS') == '1' else []
+    hooks += os.environ.get('ODBOX_EXTRA_HIPCC_FLAGS', '').split()      # tuning builds only, e.g. -DODBOX_ME_TILE_ENC=512
     os.makedirs(OBJ, exist_ok=True)
     objs = []
     for unit, extra in UNITS.items():

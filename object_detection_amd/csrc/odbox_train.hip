@@ -76,7 +76,14 @@ __device__ __forceinline__ float pair_iou(const float4 a, float a_area, const fl
 //            the packed word.  This is the HBM-bound part: 4(C+1)+20 of the 4(C+1)+36 bytes.
 // ------------------------------------------------------------------------------------------
 constexpr int ME_TILE = 256;
-constexpr int ME_TILE_STREAM = 128;      // match_encode with a dense output far beyond the Infinity Cache
+#ifndef ODBOX_ME_TILE_ENC
+#define ODBOX_ME_TILE_ENC 256               // match_encode's tile when the dense output is small (tuning: -D)
+#endif
+constexpr int ME_TILE_ENC = ODBOX_ME_TILE_ENC;
+#ifndef ODBOX_ME_TILE_STREAM
+#define ODBOX_ME_TILE_STREAM 128
+#endif
+constexpr int ME_TILE_STREAM = ODBOX_ME_TILE_STREAM;      // match_encode with a dense output far beyond the Infinity Cache
 constexpr int ME_GCHUNK = 512;
 
 // Phases 1 and 2 of the matcher for the calling thread's anchor n0 + threadIdx.x of image b:
@@ -94,7 +101,10 @@ struct TileMatch {
 // `early` is called once by every thread after the block's first global loads (anchor, first GT
 // chunk) have been consumed and before any of the matching arithmetic: work issued there (the
 // dense zero stream of match_encode_kernel) drains while the VALUs do the match.
-template <int TILE, typename EarlyWork>
+// REDUCE_LATE: the wave's bounding-box reduction runs after `early` (so it, too, overlaps what was
+// issued there: 34.5 vs 34.9 us for match+encode on config 2) instead of before the GT staging
+// (better for the loss kernel, whose prefetched score load is in flight meanwhile: 45.0 vs 45.9 us).
+template <int TILE, bool REDUCE_LATE, typename EarlyWork>
 __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ anchors,
                                                 const float4 *__restrict__ gt_boxes,
                                                 const int32_t *__restrict__ gt_labels, uint32_t b, uint32_t n0, int N,
@@ -119,7 +129,17 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
     float wx0 = live ? a.x : INFINITY, wy0 = live ? a.y : INFINITY;
     float wx1 = live ? a.z : -INFINITY, wy1 = live ? a.w : -INFINITY;
     float wmin_area = live ? a_area : INFINITY;
-    bool can_skip_zero = false;
+    auto reduce_box = [&] {
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            wx0 = fminf(wx0, __shfl_xor(wx0, off));
+            wy0 = fminf(wy0, __shfl_xor(wy0, off));
+            wx1 = fmaxf(wx1, __shfl_xor(wx1, off));
+            wy1 = fmaxf(wy1, __shfl_xor(wy1, off));
+            wmin_area = fminf(wmin_area, __shfl_xor(wmin_area, off));
+        }
+    };
+    if (!REDUCE_LATE) reduce_box();
 
     // ---- phase 1: argmax_g IoU ------------------------------------------------------------
     int best = 0;
@@ -136,21 +156,14 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
             s_gt[g] = gb;
             s_ga[g] = make_float2(area, gmax < 0.0f ? 1.0f : 0.0f);
         }
+        // every global load issued so far has been consumed: from here to the label / box gathers at
+        // the end the match is VALU and LDS work only, so memory work issued now overlaps it
         if (g0 == 0) {
-            // every global load issued so far has been consumed: from here to the label / box gathers
-            // at the end the match is VALU and LDS work only, so memory work issued now overlaps it
             early();
-#pragma unroll
-            for (int off = 1; off < WAVE; off <<= 1) {
-                wx0 = fminf(wx0, __shfl_xor(wx0, off));
-                wy0 = fminf(wy0, __shfl_xor(wy0, off));
-                wx1 = fmaxf(wx1, __shfl_xor(wx1, off));
-                wy1 = fmaxf(wy1, __shfl_xor(wy1, off));
-                wmin_area = fminf(wmin_area, __shfl_xor(wmin_area, off));
-            }
-            can_skip_zero = wmin_area >= 0.0f;         // false also for NaN
+            if (REDUCE_LATE) reduce_box();
         }
         __syncthreads();
+        const bool can_skip_zero = wmin_area >= 0.0f;      // false also for NaN
         // this wave's work list: 64 GT rows per step, one per lane, order preserved
         uint32_t nlist = 0;
         for (int gs = 0; gs < cnt; gs += WAVE) {
@@ -218,14 +231,14 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
 // beyond it (cfg 3: 2.2 GB per GPU) 6 % faster bypassing it.  The streaming variant also runs
 // 128-anchor tiles (cfg 3), the small launches prefer 256 (cfg 2: 128 and 512 are both slower).
 template <bool STREAM>
-__global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE) void match_encode_kernel(
+__global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE_ENC) void match_encode_kernel(
     const float4 *__restrict__ anchors, const float4 *__restrict__ gt_boxes,
     const int32_t *__restrict__ gt_labels, int N, int G, int C, float img_h, float img_w,
     float neg_thr, float pos_thr, float *__restrict__ out_reg, float *__restrict__ out_lab,
     int32_t *__restrict__ out_idx, int8_t *__restrict__ out_state, float *__restrict__ out_iou,
     uint32_t tiles_per_image, uint32_t d_magic)
 {
-    constexpr int TILE = STREAM ? ME_TILE_STREAM : ME_TILE;
+    constexpr int TILE = STREAM ? ME_TILE_STREAM : ME_TILE_ENC;
     __shared__ float s_reg[TILE * 5];
     (void)d_magic;
 
@@ -263,8 +276,8 @@ __global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE) void match_encod
         if (tid < count - done) lab_p[done + tid] = 0.0f;
     };
 
-    const TileMatch tm = match_tile<TILE>(anchors, gt_boxes, gt_labels, b, n0, N, G, C, img_h, img_w, neg_thr, pos_thr,
-                                          zero_stream);
+    const TileMatch tm = match_tile<TILE, true>(anchors, gt_boxes, gt_labels, b, n0, N, G, C, img_h, img_w, neg_thr, pos_thr,
+                                                zero_stream);
     const float4 a = tm.a;
     const float best_iou = tm.best_iou;
     const int best = tm.best, state = tm.state, label = tm.label;
@@ -500,8 +513,8 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     vec_t cur = IO::fill(0.5f);
     if (d >= VEC && nvec) cur = pv4[min(tid, nvec - 1)];
 
-    const TileMatch tm = match_tile<ME_TILE>(anchors, gt_boxes, gt_labels, b, n0, N, G, C, img_h, img_w, neg_thr, pos_thr,
-                                             [] {});
+    const TileMatch tm = match_tile<ME_TILE, false>(anchors, gt_boxes, gt_labels, b, n0, N, G, C, img_h, img_w, neg_thr,
+                                                    pos_thr, [] {});
     s_live[tid] = tm.live && tm.state != -1 ? (tm.state == 1 ? -1.0f : 1.0f) : 0.0f;
     s_top[tid] = 0ull;
     // metric.py:128-130 (CategoricalAccuracy over the foreground anchors) rides on the stream: a
@@ -838,7 +851,7 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
     const uint32_t magic = d == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / d);
     // dense labels beyond twice the 256 MB Infinity Cache: bypass it, smaller tiles (see match_encode_kernel)
     const bool stream_out = out_labels && (uint64_t)B * (uint64_t)N * d * sizeof(float) > (512ull << 20);
-    const int tile = stream_out ? ME_TILE_STREAM : ME_TILE;
+    const int tile = stream_out ? ME_TILE_STREAM : ME_TILE_ENC;
     const uint64_t tiles = ((uint64_t)N + tile - 1) / tile;
     const uint64_t blocks = tiles * (uint64_t)B;
     if (blocks > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_match_encode: grid too large");
