@@ -7,6 +7,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libodbox.so')
+# A/B tuning only (tools/ab_*.sh): another build of the same library, e.g. made with ODBOX_EXTRA_HIPCC_FLAGS
+LIB_PATH = os.environ.get('ODBOX_LIBRARY', LIB_PATH)
 
 _lib = None
 

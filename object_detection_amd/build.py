@@ -24,8 +24,21 @@ UNITS = {
 HEADERS = [os.path.join(CSRC, 'odbox_common.h'), os.path.join(ROOT, 'include', 'odbox.h')]
 
 
+STAMP = os.path.join(OBJ, 'flags.txt')
+
+
+def tuning_flags():
+    # ODBOX_TUNING_HOOKS=1: the library reads the ODBOX_SCAN_* / ODBOX_NMS_DBG experiment knobs (tools/exp_*.sh)
+    hooks = ['-DODBOX_TUNING_HOOKS'] if os.environ.get('ODBOX_TUNING_HOOKS') == '1' else []
+    return hooks + os.environ.get('ODBOX_EXTRA_HIPCC_FLAGS', '').split()      # tuning builds only, e.g. -DODBOX_ME_TILE_ENC=512
+
+
 def needs_build():
     if not os.path.exists(OUT):
+        return True
+    # a library built with other flags than the ones asked for now is stale, whatever its age
+    built_with = open(STAMP).read() if os.path.exists(STAMP) else ''
+    if built_with != ' '.join(tuning_flags()):
         return True
     deps = HEADERS + [os.path.join(CSRC, u) for u in UNITS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
@@ -35,9 +48,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get('HIPCC', 'hipcc')
-    # ODBOX_TUNING_HOOKS=1: the library reads the ODBOX_SCAN_* / ODBOX_NMS_DBG experiment knobs (tools/exp_*.sh)
-    hooks = ['-DODBOX_TUNING_HOOKS'] if os.environ.get('ODBOX_TUNING_HOOKS') == '1' else []
-    hooks += os.environ.get('ODBOX_EXTRA_HIPCC_FLAGS', '').split()      # tuning builds only, e.g. -DODBOX_ME_TILE_ENC=512
+    hooks = tuning_flags()
     os.makedirs(OBJ, exist_ok=True)
     objs = []
     for unit, extra in UNITS.items():
@@ -51,6 +62,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)
+    with open(STAMP, 'w') as f:
+        f.write(' '.join(hooks))
     return OUT
 
 

@@ -347,6 +347,15 @@ __global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE_ENC) void match_e
 // ------------------------------------------------------------------------------------------
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// 16-byte score vectors in flight per thread in the loss kernels, same-box A/B on config 2
+// (tools/ab_variants.sh): fp32 forward 44.9 / 45.0 / 44.0 / 48.0 us for 1 / 2 / 4 / 8 (backward 98.8 /
+// 74.1 / 72.5 / 72.6); fp16 forward 38.9 / 38.9 / 41.0 / 45.5 (backward 52.3 / 51.9 / 55.1 / 61.0).
+#ifdef ODBOX_LOSS_PREFETCH
+constexpr int LOSS_PREFETCH_F32 = ODBOX_LOSS_PREFETCH, LOSS_PREFETCH_F16 = ODBOX_LOSS_PREFETCH;
+#else
+constexpr int LOSS_PREFETCH_F32 = 4, LOSS_PREFETCH_F16 = 2;
+#endif
+
 struct LossParams {
     float gamma, alpha, delta;
 };
@@ -430,6 +439,7 @@ struct GradScale {
 template <typename T> struct PredIO;
 template <> struct PredIO<float> {
     static constexpr uint32_t VEC = 4;
+    static constexpr int PREFETCH = LOSS_PREFETCH_F32;
     typedef v4f vec_t;
     typedef float4 box_t;
     static __device__ __forceinline__ vec_t fill(float x) { return vec_t{x, x, x, x}; }
@@ -440,6 +450,7 @@ template <> struct PredIO<float> {
 };
 template <> struct PredIO<_Float16> {
     static constexpr uint32_t VEC = 8;
+    static constexpr int PREFETCH = LOSS_PREFETCH_F16;
     typedef v8h vec_t;
     typedef v4h box_t;
     static __device__ __forceinline__ vec_t fill(float x) { const _Float16 h = (_Float16)x; return vec_t{h, h, h, h, h, h, h, h}; }
@@ -477,6 +488,7 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
 {
     using IO = PredIO<T>;
     constexpr uint32_t VEC = IO::VEC;
+    constexpr int LOSS_PREFETCH = IO::PREFETCH;
     typedef typename IO::vec_t vec_t;
     __shared__ float s_live[ME_TILE];           // |x| = 1.0: anchor counts (state != -1), 0.0 = ignored; -1.0 = foreground
     __shared__ float s_red[4][ME_TILE / WAVE];
@@ -501,8 +513,10 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
 
     // The tile's [tile_n, C] predictions are one contiguous run: 16-byte loads over the flat element
     // range (scalar head / tail for the element-aligned ends; ALIGNED = C % VEC == 0 and a 16-byte
-    // aligned tensor: no head, and a vector never straddles two anchors).  The first load is issued
-    // before the match so its latency hides behind the GT loop.
+    // aligned tensor: no head, and a vector never straddles two anchors).  The first LOSS_PREFETCH
+    // vectors of every thread are requested from inside match_tile, right after its own global
+    // loads, so that part of the stream moves while the VALUs match (the match needs the memory
+    // system for nothing else); the loop then keeps LOSS_PREFETCH loads in flight per thread.
     const uint32_t d = (uint32_t)C;
     const size_t soff = ((size_t)b * N + n0) * d;
     const T *p = pred_scores + soff;
@@ -510,11 +524,18 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     const uint32_t head = ALIGNED ? 0u : min(count, (uint32_t)(((16u - ((uintptr_t)p & 15u)) & 15u) / sizeof(T)));
     const uint32_t nvec = (count - head) / VEC;
     const vec_t *pv4 = reinterpret_cast<const vec_t *>(p + head);
-    vec_t cur = IO::fill(0.5f);
-    if (d >= VEC && nvec) cur = pv4[min(tid, nvec - 1)];
+    vec_t pre[LOSS_PREFETCH];
+#pragma unroll
+    for (int k = 0; k < LOSS_PREFETCH; ++k) pre[k] = IO::fill(0.5f);
+    auto prefetch = [&] {
+        if (d >= VEC && nvec) {
+#pragma unroll
+            for (int k = 0; k < LOSS_PREFETCH; ++k) pre[k] = pv4[min(tid + (uint32_t)k * ME_TILE, nvec - 1)];
+        }
+    };
 
     const TileMatch tm = match_tile<ME_TILE, false>(anchors, gt_boxes, gt_labels, b, n0, N, G, C, img_h, img_w, neg_thr,
-                                                    pos_thr, [] {});
+                                                    pos_thr, prefetch);
     s_live[tid] = tm.live && tm.state != -1 ? (tm.state == 1 ? -1.0f : 1.0f) : 0.0f;
     s_top[tid] = 0ull;
     // metric.py:128-130 (CategoricalAccuracy over the foreground anchors) rides on the stream: a
@@ -579,8 +600,7 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
         };
         if (tid < head) one(tid);
         if (d >= VEC) {
-            for (uint32_t v = tid; v < nvec; v += ME_TILE) {
-                const vec_t nxt = pv4[min(v + ME_TILE, nvec - 1)];   // prefetch, clamped => unconditional
+            auto process = [&](uint32_t v, const vec_t cur) {
                 const uint32_t e = head + VEC * v;
                 uint32_t q, r;
                 divmod_u32(e, d, c_magic, q, r);
@@ -634,7 +654,15 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
                     // waited for (s_waitcnt) in front of it -- an inline-asm store raced with the fix-up.
                     __builtin_nontemporal_store(IO::pack(g), reinterpret_cast<vec_t *>(gp + e));
                 }
-                cur = nxt;
+            };
+            for (uint32_t v0 = tid; v0 < nvec; v0 += LOSS_PREFETCH * ME_TILE) {
+#pragma unroll
+                for (int k = 0; k < LOSS_PREFETCH; ++k) {
+                    const uint32_t v = v0 + (uint32_t)k * ME_TILE;
+                    const vec_t cur = pre[k];
+                    pre[k] = pv4[min(v + LOSS_PREFETCH * ME_TILE, nvec - 1)];   // clamped => unconditional
+                    if (v < nvec) process(v, cur);
+                }
             }
         } else {
             for (uint32_t e = head + tid; e < head + VEC * nvec; e += ME_TILE) one(e);

@@ -32,3 +32,12 @@ for mb in (234, 245, 490, 2262):
     print(json.dumps(dict(MB=mb, fill_us=t_fill * 1e6, fill_TBs=n * 4 / t_fill / 1e12, zero_us=t_zero * 1e6,
                           zero_TBs=n * 4 / t_zero / 1e12, copy_us=t_copy * 1e6, copy_TBs=n * 4 / t_copy / 1e12)))
     del x, y, z
+
+# read ceiling for the loss kernels: a plain sum over the bytes the forward pass reads
+for mb in (120, 240, 480):
+    n = mb * 1000 * 1000 // 4
+    x = torch.rand(n, dtype=torch.float32, device=dev)
+    t = timed(lambda: x.sum())
+    t2 = timed(lambda: x.max())
+    print(json.dumps(dict(MB=mb, sum_us=t * 1e6, sum_TBs=n * 4 / t / 1e12, max_us=t2 * 1e6, max_TBs=n * 4 / t2 / 1e12)))
+    del x
