@@ -80,6 +80,20 @@ constexpr int ME_TILE = 256;
 #define ODBOX_ME_TILE_ENC 256               // match_encode's tile when the dense output is small (tuning: -D)
 #endif
 constexpr int ME_TILE_ENC = ODBOX_ME_TILE_ENC;
+#ifndef ODBOX_ZERO_STORE_MODE
+#define ODBOX_ZERO_STORE_MODE 0          // 0 = plain C++ stores for the zero stream, 1 = sc1 inline-asm stores (A/B)
+#endif
+#ifndef ODBOX_ZERO_ALIGN
+#define ODBOX_ZERO_ALIGN 128               // bytes the zero stream's vector stores are aligned to (A/B: 16)
+#endif
+constexpr uint32_t ZERO_ALIGN = ODBOX_ZERO_ALIGN;
+#ifndef ODBOX_LOSS_ALIGN
+#define ODBOX_LOSS_ALIGN 128               // bytes the loss kernels' score / gradient vectors are aligned to (A/B: 16)
+#endif
+constexpr uint32_t LOSS_ALIGN = ODBOX_LOSS_ALIGN;
+#ifndef ODBOX_STREAM_MB
+#define ODBOX_STREAM_MB 512                // dense label bytes beyond which match_encode bypasses the Infinity Cache
+#endif
 #ifndef ODBOX_ME_TILE_STREAM
 #define ODBOX_ME_TILE_STREAM 128
 #endif
@@ -254,23 +268,37 @@ __global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE_ENC) void match_e
     // not-background anchors and the one 1.0 of foreground anchors.  The zeros do not depend on the
     // match, so they are streamed (flat 16-byte stores) from inside match_tile, right after its
     // global loads, and drain while the VALUs do the matching; the few non-zero elements are
-    // patched by their anchor's thread afterwards.  Compiler-visible stores on purpose: the patch
-    // overwrites bytes of this stream, and only stores the compiler knows about are ordered by
-    // the barrier in between (see match_loss_kernel).
+    // patched by their anchor's thread afterwards, behind an explicit s_waitcnt vmcnt(0) and the block
+    // barrier: the patch overwrites bytes of this stream.
     typedef float v4f_ __attribute__((ext_vector_type(4)));
     const uint32_t d = (uint32_t)C + 1u;
     float *lab_p = out_lab ? out_lab + ((size_t)b * N + n0) * d : nullptr;
     auto zero_stream = [&] {
         if (!out_lab) return;
+        // vectors start on a 128-byte line (up to 31 scalar head elements), so every wave-wide store
+        // covers 8 whole cache lines: with tiles that begin anywhere (N not a multiple of 32) the
+        // 16-byte-aligned version wrote two partial lines per instruction
         const uint32_t count = tile_n * d;
-        const uint32_t head = min(count, (uint32_t)((16u - ((uintptr_t)lab_p & 15u)) & 15u) >> 2);
+        const uint32_t head = min(count, (uint32_t)((ZERO_ALIGN - ((uintptr_t)lab_p & (ZERO_ALIGN - 1u))) & (ZERO_ALIGN - 1u)) >> 2);
         const uint32_t nvec = (count - head) >> 2;
         if (tid < head) lab_p[tid] = 0.0f;
         const v4f_ z = {0.0f, 0.0f, 0.0f, 0.0f};
         for (uint32_t v = tid; v < nvec; v += TILE) {
             v4f_ *dst = reinterpret_cast<v4f_ *>(lab_p + head + 4 * v);
+#if ODBOX_ZERO_STORE_MODE == 1
+            // Device-scope (sc1) stores, kept for A/B only.  A bare fill of config 2's label tensor in this
+            // block shape takes 25.9 us with them against 27.9 us plain (tools/exp/fill_shapes.hip), but
+            // inside this kernel they lose on the config-2 grid at every batch size from 32 to 100
+            // (B 64: 37.2 vs 34.4 us; tools/exp_store_policy.py) and win only on config 1 (21.4 vs 22.2).
+            // (Inline asm is invisible to the compiler's s_waitcnt bookkeeping; safe here because these
+            // stores are OLDER than every load that follows and the explicit s_waitcnt vmcnt(0) in
+            // front of the block barrier covers the patch.)
+            if (STREAM) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(dst), "v"(z) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(z) : "memory");
+#else
             if (STREAM) __builtin_nontemporal_store(z, dst);
             else *dst = z;
+#endif
         }
         const uint32_t done = head + 4 * nvec;
         if (tid < count - done) lab_p[done + tid] = 0.0f;
@@ -314,7 +342,7 @@ __global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE_ENC) void match_e
     if (out_reg) {
         float *p = out_reg + ((size_t)b * N + n0) * 5;
         const uint32_t count = tile_n * 5;
-        const uint32_t head = min(count, (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) >> 2);
+        const uint32_t head = min(count, (uint32_t)((ZERO_ALIGN - ((uintptr_t)p & (ZERO_ALIGN - 1u))) & (ZERO_ALIGN - 1u)) >> 2);
         const uint32_t nvec = (count - head) >> 2;
         if (tid < head) p[tid] = s_reg[tid];
         for (uint32_t v = tid; v < nvec; v += TILE) {
@@ -521,7 +549,9 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     const size_t soff = ((size_t)b * N + n0) * d;
     const T *p = pred_scores + soff;
     const uint32_t count = tile_n * d;
-    const uint32_t head = ALIGNED ? 0u : min(count, (uint32_t)(((16u - ((uintptr_t)p & 15u)) & 15u) / sizeof(T)));
+    // vectors start on a LOSS_ALIGN-byte line (scalar head elements before it), so a wave-wide access
+    // covers whole cache lines; with ALIGNED the head is a multiple of VEC and rows stay unstraddled
+    const uint32_t head = min(count, (uint32_t)(((LOSS_ALIGN - ((uintptr_t)p & (LOSS_ALIGN - 1u))) & (LOSS_ALIGN - 1u)) / sizeof(T)));
     const uint32_t nvec = (count - head) / VEC;
     const vec_t *pv4 = reinterpret_cast<const vec_t *>(p + head);
     vec_t pre[LOSS_PREFETCH];
@@ -878,7 +908,7 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
     const uint32_t d = (uint32_t)C + 1u;
     const uint32_t magic = d == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / d);
     // dense labels beyond twice the 256 MB Infinity Cache: bypass it, smaller tiles (see match_encode_kernel)
-    const bool stream_out = out_labels && (uint64_t)B * (uint64_t)N * d * sizeof(float) > (512ull << 20);
+    const bool stream_out = out_labels && (uint64_t)B * (uint64_t)N * d * sizeof(float) > ((uint64_t)ODBOX_STREAM_MB << 20);
     const int tile = stream_out ? ME_TILE_STREAM : ME_TILE_ENC;
     const uint64_t tiles = ((uint64_t)N + tile - 1) / tile;
     const uint64_t blocks = tiles * (uint64_t)B;
