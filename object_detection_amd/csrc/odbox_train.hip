@@ -254,14 +254,15 @@ __global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE_ENC) void match_e
     const int32_t *__restrict__ gt_labels, int N, int G, int C, float img_h, float img_w,
     float neg_thr, float pos_thr, float *__restrict__ out_reg, float *__restrict__ out_lab,
     int32_t *__restrict__ out_idx, int8_t *__restrict__ out_state, float *__restrict__ out_iou,
-    uint32_t tiles_per_image, uint32_t d_magic)
+    uint32_t tiles_per_image, uint32_t remap)
 {
     constexpr int TILE = STREAM ? ME_TILE_STREAM : ME_TILE_ENC;
     __shared__ float s_reg[TILE * 5];
-    (void)d_magic;
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
+    // neighbouring tiles on one XCD (shared L2) pays when the output streams to HBM (config 3: 358 vs
+    // 388 us); while it fits the Infinity Cache the plain order is 1-3 % faster (config 2: 33.3 vs 33.8 us)
+    const uint32_t blk = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const uint32_t b = blk / tiles_per_image;
     const uint32_t n0 = (blk - b * tiles_per_image) * TILE;
     const uint32_t n = n0 + tid;
@@ -914,9 +915,20 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
         return fail(ODBOX_EINVAL, "odbox_match_encode: anchors / gt_boxes must be 16-byte aligned");
     if (B == 0 || N == 0) return 0;
     const uint32_t d = (uint32_t)C + 1u;
-    const uint32_t magic = d == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / d);
-    // dense labels beyond twice the 256 MB Infinity Cache: bypass it, smaller tiles (see match_encode_kernel)
-    const bool stream_out = out_labels && (uint64_t)B * (uint64_t)N * d * sizeof(float) > ((uint64_t)ODBOX_STREAM_MB << 20);
+    // dense labels beyond twice the 256 MB Infinity Cache: bypass it, smaller tiles (see match_encode_kernel).
+    // Tile order: whole images per XCD (xcd_remap) is balanced by construction and keeps an image's tiles
+    // on one L2; it is the rule.  The plain order is 1-3 % faster for a launch that is bound by a store
+    // stream the Infinity Cache absorbs (same-box sweep: wins up to 344 MB, loses from 413 MB), but it
+    // maps tile t to XCD t % 8, which is badly unbalanced when the per-tile match cost matters and
+    // tiles_per_image is a multiple of 8 (config 4: 622 vs 412 us).  So: plain order only when the match
+    // is cheap (G <= 64: one culling step, hidden under the stores) and the labels are at most 384 MB.
+    const uint64_t label_bytes = out_labels ? (uint64_t)B * (uint64_t)N * d * sizeof(float) : 0;
+    const bool stream_out = label_bytes > ((uint64_t)ODBOX_STREAM_MB << 20);
+#ifdef ODBOX_ENC_REMAP_FORCE
+    const uint32_t remap = ODBOX_ENC_REMAP_FORCE;
+#else
+    const uint32_t remap = (label_bytes > 0 && label_bytes <= (384ull << 20) && G <= 64) ? 0u : 1u;
+#endif
     const int tile = stream_out ? ME_TILE_STREAM : ME_TILE_ENC;
     const uint64_t tiles = ((uint64_t)N + tile - 1) / tile;
     const uint64_t blocks = tiles * (uint64_t)B;
@@ -925,7 +937,7 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
         hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(tile), 0, (hipStream_t)stream,
                            (const float4 *)anchors, (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w,
                            neg_thr, pos_thr, out_regression, out_labels, out_match_idx, out_state, out_max_iou,
-                           (uint32_t)tiles, magic);
+                           (uint32_t)tiles, remap);
     };
     if (stream_out) launch(match_encode_kernel<true>);
     else launch(match_encode_kernel<false>);
