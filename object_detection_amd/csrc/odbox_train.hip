@@ -546,7 +546,9 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     }
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
+    // whole images per XCD, back to front like match_encode_kernel (same-box A/B on config 2: forward
+    // 43.9 -> 42.7 us, fp16 forward 38.8 -> 37.4 us; the plain block order is slower with gradients)
+    const uint32_t blk = gridDim.x - 1u - xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t b = blk / tiles_per_image;
     const uint32_t n0 = (blk - b * tiles_per_image) * ME_TILE;
     const uint32_t tile_n = min((uint32_t)ME_TILE, (uint32_t)N - n0);
