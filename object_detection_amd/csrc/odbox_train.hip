@@ -67,13 +67,19 @@ __device__ __forceinline__ float pair_iou(const float4 a, float a_area, const fl
 //
 // One block = one tile of ME_TILE anchors of one image.
 //   phase 1  thread = anchor: GT boxes of the image staged in LDS (box, area, pad flag) in
-//            chunks of ME_GCHUNK, IoU + strict-> argmax in registers (first max wins).
-//   phase 2  thresholds, out-of-image test, label, offsets; compact outputs stored directly;
-//            5 regression floats and a packed (label, state) word staged in LDS.
+//            chunks of ME_GCHUNK, per-wave culling of the rows that cannot overlap, IoU +
+//            strict-> argmax in registers (first max wins).
+//   phase 2  thresholds, out-of-image test, label, offsets; compact outputs stored directly; the
+//            5 regression floats staged in LDS.
 //   phase 3  the two dense outputs of the tile are contiguous in memory ([tile,5] and
-//            [tile,C+1] floats): the block streams them as 16-byte stores over the FLAT element
-//            range (head/tail handled with scalar stores), rebuilding each one-hot element from
-//            the packed word.  This is the HBM-bound part: 4(C+1)+20 of the 4(C+1)+36 bytes.
+//            [tile,C+1] floats) and written as 16-byte stores over the FLAT element range, aligned
+//            to cache lines (head/tail scalar).  The [tile,C+1] block is almost all zeros, and
+//            zeros do not depend on the match: they are issued from INSIDE phase 1, right after its
+//            global loads, and drain while the VALUs match; the non-zero elements (state, the
+//            one 1.0) are patched per anchor afterwards.  This stream is the HBM-bound part:
+//            4(C+1)+20 of the 4(C+1)+36 bytes per anchor.
+// The #defines below are tuning knobs for A/B builds (ODBOX_EXTRA_HIPCC_FLAGS, tools/ab_variants.sh);
+// the defaults are the measured winners.
 // ------------------------------------------------------------------------------------------
 constexpr int ME_TILE = 256;
 #ifndef ODBOX_ME_TILE_ENC
