@@ -83,6 +83,21 @@ def main():
             row['Tops'] = ops / t / 1e12
             row['frac_valu_nonpacked'] = ops / t / VALU_OPS
         rows.append(row)
+        if cfg == 2:
+            # the optional compact-output mode (match index, state, 4 offsets + state column =
+            # 25 B per anchor instead of 344), reported separately: what the matcher costs without the dense labels
+            idx = torch.empty((B, N), dtype=torch.int32, device=dev)
+            state = torch.empty((B, N), dtype=torch.int8, device=dev)
+
+            def step_compact():
+                rc = lib.odbox_match_encode(anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C, float(c['S']),
+                                            float(c['S']), 0.4, 0.5, reg.data_ptr(), None, idx.data_ptr(), state.data_ptr(),
+                                            None, st)
+                assert rc == 0
+            t = event_time(step_compact, args.iters)
+            byts = B * (N * (16 + 20 + 5) + 20 * G)
+            rows.append(dict(cfg='2_compact', B=B, N=N, G=G, C=C, us=t * 1e6, img_s=B / t, GBs=byts / t / 1e9,
+                             frac_hbm=byts / t / 1e9 / HBM))
     # fused matcher + loss on the cfg-2 batch (forward, and forward + gradients)
     if 2 in args.cfg:
         c = workloads.CONFIGS[2]
