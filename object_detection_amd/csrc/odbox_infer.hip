@@ -442,13 +442,19 @@ __device__ __forceinline__ void wave_sort_to_lds(const uint64_t *src, uint32_t n
 constexpr int SORT_THREADS = 1024;
 constexpr uint32_t SORT_LDS_CAP = 16384;   // keys a block sorts in LDS (128 KiB); more: in global memory
 constexpr uint32_t NMS_SEG_LDS = 512;      // keys one NMS wave sorts by itself; bigger segments: block sort
-constexpr int NMS_COOP_MIN = 128;          // segments above this (and <= NMS_SEG_LDS): nms_coop_kernel, one block each
+#ifndef ODBOX_NMS_COOP_MIN
+#define ODBOX_NMS_COOP_MIN 128
+#endif
+constexpr int NMS_COOP_MIN = ODBOX_NMS_COOP_MIN;          // segments above this (and <= NMS_SEG_LDS): nms_coop_kernel, one block each
 
 // kernel 2: counting sort of one image's candidate keys by class (LDS histogram -> scan ->
 // scatter); writes the class segment starts.  When one class holds more keys than an NMS wave
 // sorts on its own (NMS_SEG_LDS) the block also sorts the whole list -- it is grouped by class
 // already, so a full key sort puts every segment in visiting order -- and flags the image.
-constexpr int PART_THREADS = 512;
+#ifndef ODBOX_PART_THREADS
+#define ODBOX_PART_THREADS 512
+#endif
+constexpr int PART_THREADS = ODBOX_PART_THREADS;
 
 __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
     const int *__restrict__ cand_count, const uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out,
@@ -1062,7 +1068,10 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
 // every wave sorts 128-key chunks in registers, then chunk pairs are merged keeping the lower
 // half (min(A[e], B[127-e]) is bitonic and holds the 128 smallest of both; one register merge
 // sorts it) -- log2(chunks) rounds instead of a full sort of the list.
-constexpr int FIN_THREADS = 1024;
+#ifndef ODBOX_FIN_THREADS
+#define ODBOX_FIN_THREADS 1024
+#endif
+constexpr int FIN_THREADS = ODBOX_FIN_THREADS;
 constexpr uint32_t FIN_CHUNK = 128;
 
 __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
