@@ -250,3 +250,21 @@ def test_unaligned_dense_outputs_and_odd_shapes(C, N, off):
     # nothing outside the views was touched
     assert float(reg_buf[:off].min()) == 7.0 and float(reg_buf[off + B * N * 5:].min()) == 7.0
     assert float(lab_buf[:off].min()) == 7.0 and float(lab_buf[off + B * N * (C + 1):].min()) == 7.0
+
+
+def test_streaming_variant_with_off_grid_tiles():
+    """Dense labels beyond 512 MB take the cache-bypassing variant (128-anchor tiles, nontemporal
+    zero stream, per-anchor patches); on the config-2 grid (N = 10 647) no tile starts on a cache
+    line.  B = 160 -> 552 MB of labels, compared with the C oracle element for element."""
+    anchors = O.yolo_shaped_anchors(416)
+    B = 160
+    gt, lab = workloads.match_inputs(2, batch=B)
+    got = A.match_encode(anchors, (416, 416), gt, lab, 80, dense=True, compact=True)
+    ref = c_oracle.match_encode(anchors, (416, 416), gt, lab, 80, threads=8)
+    assert got['labels'].numel() * 4 > 512 << 20
+    np.testing.assert_array_equal(cpu(got['state']), ref['state'])
+    np.testing.assert_array_equal(cpu(got['match_idx']), ref['match_idx'])
+    assert np.array_equal(cpu(got['labels']), ref['labels'])
+    reg = cpu(got['regression'])
+    np.testing.assert_array_equal(reg[..., 4], ref['regression'][..., 4])
+    np.testing.assert_allclose(reg[..., :4], ref['regression'][..., :4], rtol=1e-5, atol=0)
