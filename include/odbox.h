@@ -246,6 +246,16 @@ int odbox_restore_boxes(const float *boxes /*[B,R,4]*/, const float *scores /*[B
                         const int32_t *orig_hw /*[B,2]*/, int B, int R, int image_size,
                         double *out_boxes /*[B,R,4] f64*/, int32_t *out_count /*[B]*/, void *stream);
 
+/* ---- multi-GPU plumbing (the reference has no counterpart) ---- */
+
+/* The fixed-size detection records that ONE all-gather moves between ranks: n = images * max_ret
+ * rows of 6 words (x0, y0, x1, y1, score, label bit-cast to float).  pack: the three outputs of
+ * odbox_decode_nms -> records; unpack: the gathered records -> three tensors. */
+int odbox_pack_records(const float *boxes /*[n,4]*/, const float *scores /*[n]*/, const int32_t *labels /*[n]*/,
+                       size_t n, float *records /*[n,6]*/, void *stream);
+int odbox_unpack_records(const float *records /*[n,6]*/, size_t n, float *boxes /*[n,4]*/, float *scores /*[n]*/,
+                         int32_t *labels /*[n]*/, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,8 @@ SIGNATURES = {
     'odbox_coco_match_workspace': (_sz, [_i, _i]),
     'odbox_coco_match': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i,
                               _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'odbox_pack_records': (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    'odbox_unpack_records': (_i, [_vp, _sz, _vp, _vp, _vp, _vp]),
     'odbox_restore_boxes': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'odbox_gt_prepare_xywh': (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp]),
     'odbox_gt_prepare_poly': (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp]),

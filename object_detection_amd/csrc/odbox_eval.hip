@@ -502,6 +502,36 @@ __global__ __launch_bounds__(256) void restore_boxes_kernel(const float4 *__rest
     if (threadIdx.x == 0) out_count[b] = count;
 }
 
+// ------------------------------------------------------------------------------------------
+// Multi-GPU plumbing (no counterpart in the reference): the fixed-size records one
+// all-gather moves.  [n,4] boxes + [n] scores + [n] int32 labels <-> [n,6] words, label bit-cast.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_records_kernel(const float4 *__restrict__ boxes,
+                                                           const float *__restrict__ scores,
+                                                           const int32_t *__restrict__ labels, uint32_t n,
+                                                           float *__restrict__ rec)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 b = boxes[i];
+    float *r = rec + (size_t)i * 6;
+    r[0] = b.x; r[1] = b.y; r[2] = b.z; r[3] = b.w;
+    r[4] = scores[i];
+    r[5] = __int_as_float(labels[i]);
+}
+
+__global__ __launch_bounds__(256) void unpack_records_kernel(const float *__restrict__ rec, uint32_t n,
+                                                             float4 *__restrict__ boxes, float *__restrict__ scores,
+                                                             int32_t *__restrict__ labels)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float *r = rec + (size_t)i * 6;
+    boxes[i] = make_float4(r[0], r[1], r[2], r[3]);
+    scores[i] = r[4];
+    labels[i] = __float_as_int(r[5]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -535,6 +565,29 @@ int odbox_restore_boxes(const float *boxes, const float *scores, const int32_t *
     hipLaunchKernelGGL(restore_boxes_kernel, dim3((uint32_t)B), dim3(256), 0, (hipStream_t)stream, (const float4 *)boxes,
                        scores, orig_hw, R, (double)image_size, out_boxes, out_count);
     return launch_status("restore_boxes");
+}
+
+int odbox_pack_records(const float *boxes, const float *scores, const int32_t *labels, size_t n, float *records,
+                       void *stream)
+{
+    if (n == 0) return 0;
+    if (!boxes || !scores || !labels || !records) return fail(ODBOX_EINVAL, "odbox_pack_records: NULL pointer");
+    if (!aligned16(boxes)) return fail(ODBOX_EINVAL, "odbox_pack_records: boxes must be 16-byte aligned");
+    if (n > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_pack_records: too many records");
+    hipLaunchKernelGGL(pack_records_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)boxes, scores, labels, (uint32_t)n, records);
+    return launch_status("pack_records");
+}
+
+int odbox_unpack_records(const float *records, size_t n, float *boxes, float *scores, int32_t *labels, void *stream)
+{
+    if (n == 0) return 0;
+    if (!boxes || !scores || !labels || !records) return fail(ODBOX_EINVAL, "odbox_unpack_records: NULL pointer");
+    if (!aligned16(boxes)) return fail(ODBOX_EINVAL, "odbox_unpack_records: boxes must be 16-byte aligned");
+    if (n > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_unpack_records: too many records");
+    hipLaunchKernelGGL(unpack_records_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, records,
+                       (uint32_t)n, (float4 *)boxes, scores, labels);
+    return launch_status("unpack_records");
 }
 
 }  // extern "C"

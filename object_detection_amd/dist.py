@@ -39,12 +39,38 @@ def shard_range(batch, rank, world):
     return lo, min(lo + per, batch)
 
 
-def pack_detections(boxes, scores, labels):
-    """[b,R,4] f32, [b,R] f32, [b,R] i32 -> [b,R,6] f32 records (label bit-cast, not converted)."""
-    return torch.cat([boxes, scores.unsqueeze(-1), labels.view(torch.float32).unsqueeze(-1)], dim=-1)
+def pack_detections(boxes, scores, labels, rows=None):
+    """[b,R,4] f32, [b,R] f32, [b,R] i32 -> [rows or b, R, 6] f32 records (label bit-cast, not
+    converted; rows beyond b are zero).  One HIP launch on the GPU; torch ops for CPU tensors (the
+    gloo tests)."""
+    b, R = int(scores.shape[0]), int(scores.shape[1])
+    rows = b if rows is None else max(rows, b)
+    if boxes.is_cuda:
+        from . import _lib
+        lib = _lib.load()
+        boxes, scores, labels = boxes.contiguous(), scores.contiguous(), labels.contiguous()
+        rec = (torch.zeros if rows > b else torch.empty)((rows, R, 6), dtype=torch.float32, device=boxes.device)
+        _lib.check(lib.odbox_pack_records(_lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(labels), b * R, _lib.ptr(rec),
+                                          _lib.stream_ptr()), 'odbox_pack_records')
+        return rec
+    rec = torch.cat([boxes, scores.unsqueeze(-1), labels.view(torch.float32).unsqueeze(-1)], dim=-1)
+    if rows > b:
+        rec = torch.cat([rec, torch.zeros((rows - b, R, 6), dtype=rec.dtype, device=rec.device)], dim=0)
+    return rec.contiguous()
 
 
 def unpack_detections(records):
+    if records.is_cuda:
+        from . import _lib
+        lib = _lib.load()
+        records = records.contiguous()
+        n, R = int(records.shape[0]), int(records.shape[1])
+        boxes = torch.empty((n, R, 4), dtype=torch.float32, device=records.device)
+        scores = torch.empty((n, R), dtype=torch.float32, device=records.device)
+        labels = torch.empty((n, R), dtype=torch.int32, device=records.device)
+        _lib.check(lib.odbox_unpack_records(_lib.ptr(records), n * R, _lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(labels),
+                                            _lib.stream_ptr()), 'odbox_unpack_records')
+        return boxes, scores, labels
     boxes = records[..., 0:4].contiguous()
     scores = records[..., 4].contiguous()
     labels = records[..., 5].contiguous().view(torch.int32)
@@ -58,13 +84,8 @@ def gather_detections(boxes, scores, labels, batch=None, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return boxes, scores, labels
     world = dist.get_world_size(group)
-    rec = pack_detections(boxes, scores, labels)
-    if batch is not None:
-        per = (batch + world - 1) // world
-        if rec.shape[0] < per:
-            pad = torch.zeros((per - rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
-            rec = torch.cat([rec, pad], dim=0)
-    rec = rec.contiguous()
+    per = None if batch is None else (batch + world - 1) // world
+    rec = pack_detections(boxes, scores, labels, rows=per)
     out = torch.empty((world * rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
     dist.all_gather_into_tensor(out, rec, group=group)
     if batch is not None:

@@ -182,6 +182,8 @@ def test_every_entry_rejects_bad_arguments_without_touching_the_gpu(lib):
         ('odbox_coco_match', (p, p, p, p, p, 1, 2, 5000, 3, thr, 2, rng, 1, 100, p, p, None, None, p, p, 1 << 20, None), -1),   # G over the limit
         ('odbox_gt_prepare_xywh', (p, p, None, p, 2, 4, 512.0, 0, 0, p, p, None), -1),
         ('odbox_restore_boxes', (p, p, None, 2, 4, 512, p, p, None), -1),
+        ('odbox_pack_records', (p, p, None, 8, p, None), -1),
+        ('odbox_unpack_records', (p, 8, odd, p, p, None), -1),
         ('odbox_restore_boxes', (p, p, p, 2, 4, 0, p, p, None), -1),                                                             # image_size
         ('odbox_gt_prepare_poly', (p, p, p, p, 2, 4, 512.0, 0, 7, p, p, None), -1),                                              # mode
         ('odbox_gt_prepare_xywh', (p, p, p, p, 2, 4, 0.0, 0, 0, p, p, None), -1),                                                # image_size
