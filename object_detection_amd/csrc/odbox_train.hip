@@ -81,7 +81,10 @@ __device__ __forceinline__ float pair_iou(const float4 a, float a_area, const fl
 // The #defines below are tuning knobs for A/B builds (ODBOX_EXTRA_HIPCC_FLAGS, tools/ab_variants.sh);
 // the defaults are the measured winners.
 // ------------------------------------------------------------------------------------------
-constexpr int ME_TILE = 256;
+#ifndef ODBOX_ME_TILE
+#define ODBOX_ME_TILE 256                   // anchors per block in the loss kernels (A/B: 128 and 512 are slower)
+#endif
+constexpr int ME_TILE = ODBOX_ME_TILE;
 #ifndef ODBOX_ME_TILE_ENC
 #define ODBOX_ME_TILE_ENC 256               // match_encode's tile when the dense output is small (tuning: -D)
 #endif
