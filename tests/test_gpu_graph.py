@@ -105,7 +105,16 @@ def test_loss_eval_and_gt_preparation_replay_from_a_hip_graph():
     ws_ev = torch.empty(lib.odbox_coco_match_workspace(B, R), dtype=torch.uint8, device=dev)
     pb_out = torch.empty((B, 64, 4), device=dev)
     pl_out = torch.empty((B, 64), dtype=torch.int32, device=dev)
-    outs = (loss, gb, gs, dtm, dti, gtm, gti, rank, pb_out, pl_out)
+    # the loss backward entry point (device-resident upstream gradients / normaliser), the detection
+    # restore and the all-gather record kernels ride in the same graph
+    up = torch.tensor([2.0, 0.5], device=dev)
+    bgb, bgs = torch.empty_like(t['pb']), torch.empty_like(t['ps'])
+    hw_i = torch.tensor([[300, 400]] * B, dtype=torch.int32, device=dev)
+    rb_out = torch.empty((B, R, 4), dtype=torch.float64, device=dev)
+    rc_out = torch.empty((B,), dtype=torch.int32, device=dev)
+    rec = torch.empty((B, R, 6), device=dev)
+    ub, us, ul = torch.empty((B, R, 4), device=dev), torch.empty((B, R), device=dev), torch.empty((B, R), dtype=torch.int32, device=dev)
+    outs = (loss, gb, gs, dtm, dti, gtm, gti, rank, pb_out, pl_out, bgb, bgs, rb_out, rc_out, rec, ub, us, ul)
 
     def enqueue():
         st = _lib.stream_ptr()
@@ -121,6 +130,19 @@ def test_loss_eval_and_gt_preparation_replay_from_a_hip_graph():
         assert rc == 0, lib.odbox_last_error()
         rc = lib.odbox_gt_prepare_xywh(t['xywh'].data_ptr(), t['xl'].data_ptr(), offs.data_ptr(), hw.data_ptr(), B, 64, 512.0,
                                        0, 0, pb_out.data_ptr(), pl_out.data_ptr(), st)
+        assert rc == 0, lib.odbox_last_error()
+        rc = lib.odbox_match_loss_backward(anchors.data_ptr(), t['gt'].data_ptr(), t['lab'].data_ptr(), B, N, Gp, C, float(S),
+                                           float(S), 0.4, 0.5, t['pb'].data_ptr(), t['ps'].data_ptr(), 1.5, 0.25, 1.0,
+                                           up[0:1].data_ptr(), up[1:2].data_ptr(), loss[2:3].data_ptr(), bgb.data_ptr(),
+                                           bgs.data_ptr(), st)
+        assert rc == 0, lib.odbox_last_error()
+        rc = lib.odbox_restore_boxes(t['dt_boxes'].data_ptr(), t['dt_scores'].data_ptr(), hw_i.data_ptr(), B, R, S,
+                                     rb_out.data_ptr(), rc_out.data_ptr(), st)
+        assert rc == 0, lib.odbox_last_error()
+        rc = lib.odbox_pack_records(t['dt_boxes'].data_ptr(), t['dt_scores'].data_ptr(), t['dt_labels'].data_ptr(), B * R,
+                                    rec.data_ptr(), st)
+        assert rc == 0, lib.odbox_last_error()
+        rc = lib.odbox_unpack_records(rec.data_ptr(), B * R, ub.data_ptr(), us.data_ptr(), ul.data_ptr(), st)
         assert rc == 0, lib.odbox_last_error()
 
     side = torch.cuda.Stream()
@@ -143,3 +165,6 @@ def test_loss_eval_and_gt_preparation_replay_from_a_hip_graph():
         for a, b in zip(replayed, outs):
             assert torch.equal(a, b)
         assert float(loss[2]) > 0 and int((dtm > 0).sum()) > 0
+        # backward = explicit gradients of the sums times upstream / normaliser (one rounding apart)
+        torch.testing.assert_close(bgs, gs * (up[1] / loss[2]), rtol=1e-6, atol=0)
+        assert torch.equal(ub, t['dt_boxes']) and torch.equal(ul, t['dt_labels']) and int(rc_out.max()) > 0
