@@ -35,7 +35,7 @@ static float timed(F launch, hipStream_t st)
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) launch();
+    for (int i = 0; i < 5; ++i) launch();
     CHECK(hipStreamSynchronize(st));
     CHECK(hipEventRecord(e0, st));
     for (int i = 0; i < 20; ++i) launch();
@@ -46,9 +46,10 @@ static float timed(F launch, hipStream_t st)
     return ms * 50.0f;   // us per launch
 }
 
-int main()
+int main(int argc, char **argv)
 {
-    const size_t bytes = 64ull * 49104 * 90 * 4;            // 1.131 GB
+    // default: config 5's score tensor (1.131 GB); argv[1] = size in MB (240 = what the loss forward reads)
+    const size_t bytes = argc > 1 ? (size_t)atol(argv[1]) * 1000000ull / 16 * 16 : 64ull * 49104 * 90 * 4;
     const size_t nvec = bytes / 16;
     v4f *p;
     float *out;
