@@ -684,6 +684,9 @@ __device__ __forceinline__ float bcast_lane(float v, int j)
 // broadcast with v_readlane (an SGPR operand, no LDS latency in the serial chain); only a kept
 // list longer than that (max_ret > 128) continues in LDS.  Stops at max_ret kept (bndbox.py:172).
 constexpr int NMS_WAVES = 8;
+#ifndef ODBOX_COOP_BLOCKS
+#define ODBOX_COOP_BLOCKS 768                // blocks of the NMS launch that take the big segments cooperatively
+#endif
 constexpr int NMS_REG_KEPT = 128;
 
 __device__ __forceinline__ void nms_wave_segment(
@@ -1424,7 +1427,7 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
     const uint64_t segs = (uint64_t)B * C;
     const NmsThr nms_thr = {iou_thr, iou_thr * (1.0f - 0x1p-20f), iou_thr * (1.0f + 0x1p-20f)};
     // cooperative blocks need the full block; their list is only built by the partition kernel
-    const uint32_t coop_blocks = (waves == NMS_WAVES && pre_nms_topk == 0) ? (uint32_t)(segs < 768 ? segs : 768) : 0u;
+    const uint32_t coop_blocks = (waves == NMS_WAVES && pre_nms_topk == 0) ? (uint32_t)(segs < ODBOX_COOP_BLOCKS ? segs : ODBOX_COOP_BLOCKS) : 0u;
     size_t nms_lds = per_wave * waves;
     if (coop_blocks && nms_lds < COOP_LDS) nms_lds = COOP_LDS;
     const uint64_t nms_grid = (segs + waves - 1) / waves + coop_blocks;
