@@ -124,6 +124,23 @@ int odbox_match_loss_backward_f16(const float *anchors, const float *gt_boxes, c
                                   const float *normalizer /*three fp32 device scalars, each may be NULL*/,
                                   void *grad_boxes, void *grad_scores, void *stream);
 
+/* The same pair for bfloat16 predictions (no counterpart in the reference, which only has an fp16
+ * mode: bfloat16 is the native mixed-precision format of this GPU).  Same rules as the fp16 pair:
+ * widened on load (a 16-bit shift, exact), fp32 arithmetic, gradients rounded to nearest even. */
+int odbox_match_loss_bf16(const float *anchors, const float *gt_boxes, const int32_t *gt_labels,
+                          int B, int N, int G, int C, float img_h, float img_w, float neg_thr,
+                          float pos_thr, const void *pred_boxes /*bf16 [B,N,4]*/,
+                          const void *pred_scores /*bf16 [B,N,C]*/, float gamma, float alpha,
+                          float huber_delta, float *out_loss /*[4]*/, void *grad_boxes /*bf16 or NULL*/,
+                          void *grad_scores /*bf16 or NULL*/, void *workspace, size_t workspace_bytes,
+                          void *stream);
+int odbox_match_loss_backward_bf16(const float *anchors, const float *gt_boxes, const int32_t *gt_labels,
+                                   int B, int N, int G, int C, float img_h, float img_w, float neg_thr,
+                                   float pos_thr, const void *pred_boxes, const void *pred_scores,
+                                   float gamma, float alpha, float huber_delta,
+                                   const float *upstream_dist, const float *upstream_class,
+                                   const float *normalizer, void *grad_boxes, void *grad_scores, void *stream);
+
 /* metric.py:9-38 focal_loss(y_true, y_pred, gamma, alpha, from_logits=False, reduction='sum') on
  * dense targets (y_true == 1 marks the positive class): out[1] = sum over all n elements
  * (out has room for 4 floats: out[0], out[2], out[3] are written as 0).  grad [n] or NULL:

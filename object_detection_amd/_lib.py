@@ -32,6 +32,10 @@ SIGNATURES = {
                                   _vp, _sz, _vp]),
     'odbox_match_loss_backward_f16': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _vp, _f, _f, _f, _vp,
                                            _vp, _vp, _vp, _vp, _vp]),
+    'odbox_match_loss_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _vp, _f, _f, _f, _vp, _vp, _vp,
+                                   _vp, _sz, _vp]),
+    'odbox_match_loss_backward_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _vp, _f, _f, _f, _vp,
+                                            _vp, _vp, _vp, _vp, _vp]),
     'odbox_focal_loss_workspace': (_sz, [_sz]),
     'odbox_focal_loss': (_i, [_vp, _vp, _sz, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     'odbox_bbox_overlap': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -526,6 +526,61 @@ template <> struct PredIO<_Float16> {
     }
 };
 
+// bfloat16 (the native mixed-precision format of this GPU; the reference itself only has fp16): a
+// 16-bit storage type of our own, widened by a shift, rounded to nearest even on store (NaN kept).
+struct bf16_t {
+    uint16_t bits;
+    __device__ __forceinline__ explicit operator float() const { return __uint_as_float((uint32_t)bits << 16); }
+    __device__ __forceinline__ bf16_t() = default;
+    __device__ __forceinline__ explicit bf16_t(float f)
+    {
+        uint32_t u = __float_as_uint(f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) u |= 0x00400000u;            // NaN stays NaN
+        else u += 0x7fffu + ((u >> 16) & 1u);                             // round to nearest even
+        bits = (uint16_t)(u >> 16);
+    }
+};
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
+// two bfloat16 per dword: the low one widens with a shift, the high one with a mask
+__device__ __forceinline__ float bf16_lo(uint32_t d) { return __uint_as_float(d << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t d) { return __uint_as_float(d & 0xffff0000u); }
+// gfx950 packs and rounds (to nearest even, NaN kept) two floats in one instruction
+__device__ __forceinline__ uint32_t bf16_pair(float lo, float hi)
+{
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+template <> struct PredIO<bf16_t> {
+    static constexpr uint32_t VEC = 8;
+    static constexpr int PREFETCH = LOSS_PREFETCH_F16;
+    typedef v4u32 vec_t;
+    typedef v2u32 box_t;
+    static __device__ __forceinline__ vec_t fill(float x) { const uint32_t d = bf16_pair(x, x); return vec_t{d, d, d, d}; }
+    static __device__ __forceinline__ void unpack(vec_t v, float (&x)[8])
+    {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            x[2 * k] = bf16_lo(v[k]);
+            x[2 * k + 1] = bf16_hi(v[k]);
+        }
+    }
+    static __device__ __forceinline__ vec_t pack(const float (&g)[8])
+    {
+        return vec_t{bf16_pair(g[0], g[1]), bf16_pair(g[2], g[3]), bf16_pair(g[4], g[5]), bf16_pair(g[6], g[7])};
+    }
+    static __device__ __forceinline__ float4 load_box(const box_t *p, size_t row)
+    {
+        const v2u32 v = p[row];
+        return make_float4(bf16_lo(v[0]), bf16_hi(v[0]), bf16_lo(v[1]), bf16_hi(v[1]));
+    }
+    static __device__ __forceinline__ void store_box(box_t *p, size_t row, float4 v)
+    {
+        p[row] = v2u32{bf16_pair(v.x, v.y), bf16_pair(v.z, v.w)};
+    }
+};
+
 template <typename T, bool GRADS, bool G15, bool ALIGNED>
 __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     const float4 *__restrict__ anchors, const float4 *__restrict__ gt_boxes,
@@ -1076,6 +1131,31 @@ int odbox_match_loss_backward_f16(const float *anchors, const float *gt_boxes, c
                                     neg_thr, pos_thr, (const _Float16 *)pred_boxes, (const _Float16 *)pred_scores, gamma,
                                     alpha, huber_delta, nullptr, GradScale{upstream_dist, upstream_class, normalizer, 1},
                                     (_Float16 *)grad_boxes, (_Float16 *)grad_scores, nullptr, 0, stream);
+}
+
+int odbox_match_loss_bf16(const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B, int N, int G,
+                          int C, float img_h, float img_w, float neg_thr, float pos_thr, const void *pred_boxes,
+                          const void *pred_scores, float gamma, float alpha, float huber_delta, float *out_loss,
+                          void *grad_boxes, void *grad_scores, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!out_loss) return fail(ODBOX_EINVAL, "odbox_match_loss_bf16: NULL pointer");
+    return match_loss_run<bf16_t>("odbox_match_loss_bf16", anchors, gt_boxes, gt_labels, B, N, G, C, img_h, img_w, neg_thr,
+                                  pos_thr, (const bf16_t *)pred_boxes, (const bf16_t *)pred_scores, gamma, alpha,
+                                  huber_delta, out_loss, GradScale{nullptr, nullptr, nullptr, 0}, (bf16_t *)grad_boxes,
+                                  (bf16_t *)grad_scores, workspace, workspace_bytes, stream);
+}
+
+int odbox_match_loss_backward_bf16(const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B, int N,
+                                   int G, int C, float img_h, float img_w, float neg_thr, float pos_thr,
+                                   const void *pred_boxes, const void *pred_scores, float gamma, float alpha,
+                                   float huber_delta, const float *upstream_dist, const float *upstream_class,
+                                   const float *normalizer, void *grad_boxes, void *grad_scores, void *stream)
+{
+    if (!grad_boxes || !grad_scores) return fail(ODBOX_EINVAL, "odbox_match_loss_backward_bf16: NULL pointer");
+    return match_loss_run<bf16_t>("odbox_match_loss_backward_bf16", anchors, gt_boxes, gt_labels, B, N, G, C, img_h, img_w,
+                                  neg_thr, pos_thr, (const bf16_t *)pred_boxes, (const bf16_t *)pred_scores, gamma,
+                                  alpha, huber_delta, nullptr, GradScale{upstream_dist, upstream_class, normalizer, 1},
+                                  (bf16_t *)grad_boxes, (bf16_t *)grad_scores, nullptr, 0, stream);
 }
 
 size_t odbox_focal_loss_workspace(size_t n)

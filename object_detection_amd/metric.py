@@ -87,14 +87,18 @@ def focal_loss(y_true, y_pred, gamma: float = 1.5, alpha: float = 0.25, from_log
 def _pred_dtype(pred_bboxes, pred_scores):
     """fp16 predictions (the reference's --use_fp16 / mixed_float16 run, detection.py:296-300) go to
     the *_f16 entry points as they are; anything else is computed from fp32 tensors."""
-    if (isinstance(pred_bboxes, torch.Tensor) and isinstance(pred_scores, torch.Tensor)
-            and pred_bboxes.dtype == torch.float16 and pred_scores.dtype == torch.float16):
-        return torch.float16
+    if isinstance(pred_bboxes, torch.Tensor) and isinstance(pred_scores, torch.Tensor):
+        for dt in (torch.float16, torch.bfloat16):          # bfloat16: this GPU's native mixed-precision format
+            if pred_bboxes.dtype == dt and pred_scores.dtype == dt:
+                return dt
     return torch.float32
 
 
+_SUFFIX = {torch.float32: '', torch.float16: '_f16', torch.bfloat16: '_bf16'}
+
+
 def _entry(lib, name, dtype):
-    return getattr(lib, name + ('_f16' if dtype == torch.float16 else ''))
+    return getattr(lib, name + _SUFFIX[dtype])
 
 
 def _loss_args(lib, anchors, image_hw, gt, lab, B, N, G, C, neg, pos, pb, ps):

@@ -149,7 +149,23 @@ def main():
                                                    float(c['S']), float(c['S']), 0.4, 0.5, hb.data_ptr(), hs.data_ptr(),
                                                    1.5, 0.25, 1.0, scale[0:1].data_ptr(), scale[1:2].data_ptr(), out[2:3].data_ptr(), ghb.data_ptr(), ghs.data_ptr(), st)
             assert rc == 0
-        for name, fn, mult in (('2_loss_fwd_f16', step_h_fwd, 1), ('2_loss_backward_f16', step_h_bwd, 2)):
+        bb, bs = pb.bfloat16(), ps.bfloat16()
+        gbb, gbs = torch.empty_like(bb), torch.empty_like(bs)
+
+        def step_b_fwd():
+            rc = lib.odbox_match_loss_bf16(anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C, float(c['S']),
+                                           float(c['S']), 0.4, 0.5, bb.data_ptr(), bs.data_ptr(), 1.5, 0.25, 1.0,
+                                           out.data_ptr(), None, None, ws.data_ptr(), ws.numel(), st)
+            assert rc == 0
+
+        def step_b_bwd():
+            rc = lib.odbox_match_loss_backward_bf16(anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C,
+                                                    float(c['S']), float(c['S']), 0.4, 0.5, bb.data_ptr(), bs.data_ptr(),
+                                                    1.5, 0.25, 1.0, scale[0:1].data_ptr(), scale[1:2].data_ptr(),
+                                                    out[2:3].data_ptr(), gbb.data_ptr(), gbs.data_ptr(), st)
+            assert rc == 0
+        for name, fn, mult in (('2_loss_fwd_f16', step_h_fwd, 1), ('2_loss_backward_f16', step_h_bwd, 2),
+                               ('2_loss_fwd_bf16', step_b_fwd, 1), ('2_loss_backward_bf16', step_b_bwd, 2)):
             t = event_time(fn, args.iters)
             byts = B * (N * 16 + mult * N * (8 + 2 * C) + 20 * G)
             rows.append(dict(cfg=name, B=B, N=N, G=G, C=C, us=t * 1e6, img_s=B / t, GBs=byts / t / 1e9,
