@@ -86,8 +86,15 @@ def gather_detections(boxes, scores, labels, batch=None, group=None):
     world = dist.get_world_size(group)
     per = None if batch is None else (batch + world - 1) // world
     rec = pack_detections(boxes, scores, labels, rows=per)
-    out = torch.empty((world * rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
-    dist.all_gather_into_tensor(out, rec, group=group)
+    if rec.is_cuda and dist.get_backend(group) == 'gloo':
+        # rehearsal of the N > 1 path on a machine without RCCL peers (tests/test_zy_gpu_dist2.py: two ranks
+        # on one GPU): gloo moves host memory, so the records are staged through it
+        host = torch.empty((world * rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype)
+        dist.all_gather_into_tensor(host, rec.cpu(), group=group)
+        out = host.to(rec.device)
+    else:
+        out = torch.empty((world * rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
+        dist.all_gather_into_tensor(out, rec, group=group)
     if batch is not None:
         out = out[:batch]
     return unpack_detections(out)
