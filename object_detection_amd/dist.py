@@ -23,7 +23,8 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # ODBOX_DIST_BACKEND=gloo: rehearse the multi-rank path where RCCL has no peers (several ranks on one GPU)
+            backend = os.environ.get('ODBOX_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         kwargs = {}
         if backend == 'nccl':
             kwargs['device_id'] = torch.device('cuda', torch.cuda.current_device())
