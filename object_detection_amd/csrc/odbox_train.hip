@@ -90,7 +90,7 @@ constexpr int ME_TILE = ODBOX_ME_TILE;
 #endif
 constexpr int ME_TILE_ENC = ODBOX_ME_TILE_ENC;
 #ifndef ODBOX_ZERO_STORE_MODE
-#define ODBOX_ZERO_STORE_MODE 2          // zero stream: 0 = C++ stores (plain / nontemporal), 1 = sc1 inline-asm stores in both variants, 2 = asm `sc1 nt` in the cache-bypassing variant only (config 3: 358 -> 355 us, 1 GB on the config-2 grid: 197 -> 193 us)
+#define ODBOX_ZERO_STORE_MODE 0          // zero stream: 0 = C++ stores (plain / nontemporal), 1 = sc1 inline-asm stores in both variants, 2 = asm `sc1 nt` in the cache-bypassing variant only (A/B: config 3 358 -> 355 us; not used)
 #endif
 #ifndef ODBOX_ZERO_ALIGN
 #define ODBOX_ZERO_ALIGN 128               // bytes the zero stream's vector stores are aligned to (A/B: 16)
