@@ -89,9 +89,6 @@ constexpr int ME_TILE = ODBOX_ME_TILE;
 #define ODBOX_ME_TILE_ENC 256               // match_encode's tile when the dense output is small (tuning: -D)
 #endif
 constexpr int ME_TILE_ENC = ODBOX_ME_TILE_ENC;
-#ifndef ODBOX_ZERO_STORE_MODE
-#define ODBOX_ZERO_STORE_MODE 0          // zero stream: 0 = C++ stores (plain / nontemporal), 1 = sc1 inline-asm stores in both variants, 2 = asm `sc1 nt` in the cache-bypassing variant only (A/B: config 3 358 -> 355 us; not used)
-#endif
 #ifndef ODBOX_ZERO_ALIGN
 #define ODBOX_ZERO_ALIGN 128               // bytes the zero stream's vector stores are aligned to (A/B: 16)
 #endif
@@ -305,23 +302,12 @@ __global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE_ENC) void match_e
         if (!first && tid < head) lab_p[tid] = 0.0f;
         for (uint32_t v = (first ? 0u : lead) + tid; v < (first ? lead : nvec); v += TILE) {
             v4f_ *dst = reinterpret_cast<v4f_ *>(lab_p + head + 4 * v);
-#if ODBOX_ZERO_STORE_MODE == 1
-            // Device-scope (sc1) stores, kept for A/B only.  A bare fill of config 2's label tensor in this
-            // block shape takes 25.9 us with them against 27.9 us plain (tools/exp/fill_shapes.hip), but
-            // inside this kernel they lose on the config-2 grid at every batch size from 32 to 100
-            // (B 64: 37.2 vs 34.4 us; tools/exp_store_policy.py) and win only on config 1 (21.4 vs 22.2).
-            // (Inline asm is invisible to the compiler's s_waitcnt bookkeeping; safe here because these
-            // stores are OLDER than every load that follows and the explicit s_waitcnt vmcnt(0) in
-            // front of the block barrier covers the patch.)
-            if (STREAM) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(dst), "v"(z) : "memory");
-            else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(z) : "memory");
-#elif ODBOX_ZERO_STORE_MODE == 2
-            if (STREAM) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(dst), "v"(z) : "memory");
-            else *dst = z;
-#else
+            // compiler-visible stores only: the patch below overwrites bytes of this stream.  (Device-scope
+            // sc1 stores from inline asm win a bare fill -- 25.9 vs 27.9 us for config 2's labels,
+            // tools/exp/fill_shapes.hip -- but lose inside this kernel on the config-2 grid, B 64: 37.2 vs
+            // 34.4 us; `sc1 nt` gains 1 % on config 3.  Neither is worth a store the compiler cannot see.)
             if (STREAM) __builtin_nontemporal_store(z, dst);
             else *dst = z;
-#endif
         }
         const uint32_t done = head + 4 * nvec;
         if (!first && tid < count - done) lab_p[done + tid] = 0.0f;
