@@ -17,13 +17,11 @@ resident in HBM.  Images are independent, so ranks hold different images and exc
                 + one RCCL all-gather of the detections when N > 1), reported beside it.
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
 import time
 
-import numpy as np
 import torch
 import torch.distributed as dist
 
