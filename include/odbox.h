@@ -82,6 +82,24 @@ int odbox_match_loss(const float *anchors /*[N,4]*/, const float *gt_boxes /*[B,
                      float *grad_boxes /*[B,N,4] or NULL*/, float *grad_scores /*[B,N,C] or NULL*/,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* odbox_match_loss for callers that cannot allocate.  No counterpart in the reference: it exists for
+ * code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc, which can
+ * neither size nor own a workspace.  Same arguments, kernels and results as odbox_match_loss, minus
+ * the workspace: the per-tile partial sums live in a 1 MiB array in the library's own device memory
+ * (one copy per GPU, held until the process ends), whose address is looked up once per device on
+ * the first call there (make that first call outside graph capture, with the stream's device
+ * current).  Limit: B * ceil(N / 256) <= ODBOX_NOALLOC_MAX_TILES, else ODBOX_ENOSPC.  The call
+ * itself allocates nothing.  Every call on one GPU shares that GPU's array: calls that overlap on
+ * one GPU (different streams without an ordering between them) race; one stream is always fine. */
+#define ODBOX_NOALLOC_MAX_TILES 65536
+int odbox_match_loss_noalloc(const float *anchors /*[N,4]*/, const float *gt_boxes /*[B,G,4]*/,
+                             const int32_t *gt_labels /*[B,G]*/, int B, int N, int G, int C,
+                             float img_h, float img_w, float neg_thr, float pos_thr,
+                             const float *pred_boxes /*[B,N,4]*/, const float *pred_scores /*[B,N,C]*/,
+                             float gamma, float alpha, float huber_delta, float *out_loss /*[4]*/,
+                             float *grad_boxes /*[B,N,4] or NULL*/, float *grad_scores /*[B,N,C] or NULL*/,
+                             void *stream);
+
 /* The backward pass of the same losses for autograd-style callers (what tf.GradientTape does to
  * metric.py:97-123 in train.py):
  *   grad_boxes  = (*upstream_dist  / n) * d dist_sum  / d pred_boxes

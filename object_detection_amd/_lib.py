@@ -26,6 +26,8 @@ SIGNATURES = {
     'odbox_match_loss_workspace': (_sz, [_i, _i]),
     'odbox_match_loss': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _vp, _f, _f, _f, _vp, _vp, _vp,
                               _vp, _sz, _vp]),
+    'odbox_match_loss_noalloc': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _vp, _f, _f, _f, _vp, _vp, _vp,
+                                      _vp]),
     'odbox_match_loss_backward': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _vp, _f, _f, _f, _vp, _vp,
                                        _vp, _vp, _vp, _vp]),
     'odbox_match_loss_f16': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _vp, _f, _f, _f, _vp, _vp, _vp,

@@ -9,6 +9,7 @@
 //
 // Reference citations are file:line under the reference tree (bioothod/object_detection).
 #include "odbox_common.h"
+#include <mutex>
 #include <type_traits>
 
 namespace odbox {
@@ -1145,6 +1146,68 @@ int odbox_match_loss_backward_bf16(const float *anchors, const float *gt_boxes, 
                                   neg_thr, pos_thr, (const bf16_t *)pred_boxes, (const bf16_t *)pred_scores, gamma,
                                   alpha, huber_delta, nullptr, GradScale{upstream_dist, upstream_class, normalizer, 1},
                                   (bf16_t *)grad_boxes, (bf16_t *)grad_scores, nullptr, 0, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// The allocation-free variant of odbox_match_loss (no counterpart in the reference): for callers
+// that cannot allocate -- code under HIP graph capture, tight serving loops, harnesses that forbid
+// hipMalloc.  The one scratch buffer of the loss path (the per-tile partial sums that
+// loss_reduce_kernel adds up in a fixed order) lives in this library's own device memory: every
+// GPU the library runs on holds its own copy of `scratch` until the process ends.
+//   - `scratch` is a host-side stand-in in host code, never a device address: its address on the
+//     current device comes from hipGetSymbolAddress, once per device, and only that pointer is
+//     handed to kernels;
+//   - nothing in it has to start at zero: every tile of a call writes its own 16 bytes before the
+//     reducer (next launch on the same stream) reads exactly those; what a previous, larger call
+//     left behind the last tile is never read;
+//   - every call on one GPU shares that GPU's array: calls that overlap on one GPU (two streams,
+//     two host threads) race.  Calls on one stream, or ordered by events, are fine.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t NOALLOC_MAX_TILES = ODBOX_NOALLOC_MAX_TILES;             // B * ceil(N / 256) of one call; 1 MiB per GPU
+static __device__ __align__(256) float scratch[NOALLOC_MAX_TILES * 4];
+
+extern "C++" {
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+float *g_scratch_ptr[MAX_DEVICES];                        // device address of `scratch`, per GPU
+
+// The current device's copy of `scratch` (set-up on the first call on that device).
+int scratch_on_current_device(const char *name, float **out)
+{
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) return fail(ODBOX_EINVAL, "%s: device ordinal %d out of range", name, dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        float *p = nullptr;
+        HIP_TRY(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(ODBOX_EHIP, "%s: hipGetSymbolAddress returned NULL", name);
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+}  // namespace
+}  // extern "C++"
+
+int odbox_match_loss_noalloc(const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B, int N, int G,
+                             int C, float img_h, float img_w, float neg_thr, float pos_thr, const float *pred_boxes,
+                             const float *pred_scores, float gamma, float alpha, float huber_delta, float *out_loss,
+                             float *grad_boxes, float *grad_scores, void *stream)
+{
+    const char *name = "odbox_match_loss_noalloc";
+    if (!out_loss) return fail(ODBOX_EINVAL, "%s: NULL pointer", name);
+    if (B < 1 || N < 1) return fail(ODBOX_EINVAL, "%s: bad shape B=%d N=%d (need B,N>=1)", name, B, N);
+    const uint64_t tiles = (((uint64_t)N + ME_TILE - 1) / ME_TILE) * (uint64_t)B;
+    if (tiles > NOALLOC_MAX_TILES)
+        return fail(ODBOX_ENOSPC, "%s: B * ceil(N / %d) = %llu tiles, the library-owned scratch holds %u; use "
+                    "odbox_match_loss with a caller workspace", name, ME_TILE, (unsigned long long)tiles, NOALLOC_MAX_TILES);
+    float *ws = nullptr;
+    if (int rc = scratch_on_current_device(name, &ws)) return rc;
+    return match_loss_run<float>(name, anchors, gt_boxes, gt_labels, B, N, G, C, img_h, img_w, neg_thr, pos_thr, pred_boxes,
+                                 pred_scores, gamma, alpha, huber_delta, out_loss, GradScale{nullptr, nullptr, nullptr, 0},
+                                 grad_boxes, grad_scores, ws, sizeof(float) * 4 * NOALLOC_MAX_TILES, stream);
 }
 
 size_t odbox_focal_loss_workspace(size_t n)

@@ -159,6 +159,8 @@ def test_every_entry_rejects_bad_arguments_without_touching_the_gpu(lib):
         ('odbox_match_encode', (p, p, None, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, None, None, None, None), -1),   # labels needed
         ('odbox_match_loss', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, p, p, None, p, 1 << 20, None), -1),   # one gradient only
         ('odbox_match_loss', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, p, None, None, p, 4, None), -3),        # workspace
+        ('odbox_match_loss_noalloc', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, None, None, None, None), -1),      # no out_loss
+        ('odbox_match_loss_noalloc', (p, p, p, 4096, 49104, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, p, None, None, None), -3),  # over the scratch limit
         ('odbox_match_loss_backward', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, p, p, p, None, p, None), -1),    # no grad_boxes
         ('odbox_match_loss_backward', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, p, p, p, odd, p, None), -1),     # alignment
         ('odbox_match_loss_backward', (p, p, p, 1, 4, 2, 0, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, None, None, None, p, p, None), -1),  # C < 1
