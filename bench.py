@@ -4,21 +4,35 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Invoked plainly with --gpus N > 1 (no WORLD_SIZE in the environment) it starts its own N ranks --
+as children, before this process touches the GPU -- relays rank 0's JSON line and exits with the
+children's status; with fewer than N GPUs visible it exits non-zero instead of running fewer ranks.
+
 A "step" is ONE pass of match+encode (odbox_match_encode: IoU matching + target encoding,
 dense [B,N,5] + [B,N,C+1] outputs) over one per-GPU batch of BASELINE.json configs[1]
 (YOLOv3-shaped 416x416 grid, 10 647 anchors, 80 classes, 20 GT boxes, batch 64 per GPU), inputs
-resident in HBM.  Images are independent, so ranks hold different images and exchange nothing
-(weak scaling).  The same JSON line carries
-  roofline      the match_encode kernel against the 8 TB/s HBM peak (algorithmic bytes / HIP-event time),
-  cpu_baseline  the oracle's C restatement timed on this host's cores on a bounded sample,
-  match_loss    SURVEY.md 8f row 1 on the same batch: matcher fused with the focal + Huber loss
-                (odbox_match_loss; the dense targets are never written), forward and forward+gradients,
-  decode_nms    the inference-side path (configs[4]: 49 104 anchors, 90 classes, 64 images per GPU,
-                + one RCCL all-gather of the detections when N > 1), reported beside it.
+resident in HBM.  Consecutive steps write DIFFERENT output buffers (OUTPUT_SETS sets, 1.2 GB in
+rotation), so no step's 245 MB of stores can be absorbed by the 256 MB Infinity Cache: `value` and
+`roofline` are rates against HBM.  The rate with ONE output set rewritten every step (what a steady
+loop that reuses its buffers sees; cache-assisted) is reported beside it as `roofline_cache_resident`.
+Images are independent, so ranks hold different images and exchange nothing (weak scaling).
+The same JSON line carries
+  roofline            the match_encode kernel against the 8 TB/s HBM peak: algorithmic bytes / mean HIP-event
+                      time per launch over the timed steps; `us_per_launch_median` = median over 10 groups of 10 steps,
+  match_encode_cfg0 / _cfg2 / _cfg3   the same kernel on configs[0] (B 8), the per-GPU share of configs[2]
+                      (B 32, 196 416 anchors, 2.26 GB per launch) and configs[3] (500 GT boxes; VALU-bound),
+  cpu_baseline        the oracle's C restatement timed on this host's cores on a bounded sample,
+  match_loss          SURVEY.md 8f row 1 on the same batch: matcher fused with the focal + Huber loss,
+  decode_nms          the inference-side path (configs[4] share: 49 104 anchors, 90 classes, 64 images per GPU,
+                      + one RCCL all-gather of the detections when N > 1).
 """
 import argparse
+import gc
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -31,8 +45,59 @@ sys.path.insert(0, ROOT)
 from object_detection_amd import _lib, anchors as A, bndbox as BB, dist as oddist, workloads  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (about 6.3 TB/s achievable)
+OUTPUT_SETS = 5                # output buffer sets in rotation for the headline: 5 x 245 MB against a 256 MB Infinity Cache
+TRAFFIC_SOURCE = ('static: profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, '
+                  'see profiles/README.md), not measured in this run')
 
 
+# ------------------------------------------------------------------------------------------------
+# launching the ranks
+# ------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """Parent side of `python bench.py --gpus N`: N children through torch.distributed.run (one rank
+    per GPU), their stdout / stderr inherited (rank 0 prints the JSON line), exit status relayed.
+    Nothing here initialises the GPU: torch.cuda.device_count() only counts."""
+    rehearsal = os.environ.get('ODBOX_DIST_BACKEND') == 'gloo'        # several ranks on one GPU / on CPU, gloo transport
+    have = torch.cuda.device_count()
+    if have < n and not rehearsal:
+        print('bench.py: --gpus %d but only %d GPU(s) visible; refusing to run fewer ranks' % (n, have), file=sys.stderr)
+        return 3
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd).returncode
+
+
+def selftest_child(args):
+    """`--selftest-child`: the launch contract without any GPU work (tests/test_bench_spawn.py): join
+    the group, MAX-reduce one value over the ranks, rank 0 prints the JSON line."""
+    os.environ.setdefault('ODBOX_DIST_BACKEND', 'gloo')
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1:
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        top = float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        top = 0.0
+    if args.selftest_child == 'fail' and rank == world - 1:
+        return 7
+    if rank == 0:
+        print(json.dumps({'selftest': True, 'n_gpus': world, 'max_rank': top}))
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
+# timing
+# ------------------------------------------------------------------------------------------------
 def yolo_grid_anchors(S=416):
     parts = []
     for size, stride in ((32, 8), (64, 16), (128, 32)):
@@ -56,22 +121,68 @@ def max_over_ranks(x, world):
 
 
 def timed(fn, steps, warmup, world):
-    """W untimed + exactly K timed calls, barrier + synchronize on both sides; returns
-    (max-over-ranks wall seconds, HIP-event seconds on the launch stream of this rank)."""
-    for _ in range(warmup):
-        fn()
+    """W untimed + exactly K timed calls fn(i), barrier + synchronize on both sides; returns
+    (max-over-ranks wall seconds, HIP-event seconds on the launch stream of this rank).  The
+    library launches on torch's current stream (_lib.stream_ptr()), which is the stream these
+    events are recorded on.  The warm-up goes through the same event / synchronize calls as the timed
+    region (a fresh box pages code in on first use: 25 ms once landed inside a 10 ms timed region),
+    and the garbage collector stays out of it."""
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
-    barrier(world)
-    t0 = time.perf_counter()
     e0.record()
-    for _ in range(steps):
-        fn()
+    for i in range(warmup):
+        fn(i)
     e1.record()
     torch.cuda.synchronize()
-    barrier(world)
-    wall = time.perf_counter() - t0
+    e0.elapsed_time(e1)
+    gc.collect()
+    gc.disable()
+    try:
+        barrier(world)
+        t0 = time.perf_counter()
+        e0.record()
+        for i in range(steps):
+            fn(warmup + i)
+        e1.record()
+        torch.cuda.synchronize()
+        barrier(world)
+        wall = time.perf_counter() - t0
+    finally:
+        gc.enable()
     return max_over_ranks(wall, world), e0.elapsed_time(e1) * 1e-3
+
+
+def per_step_median(fn, groups=10, per_group=10):
+    """Median (and min) over `groups` of the mean HIP-event time of `per_group` consecutive steps: a
+    single hiccup cannot move the figure, and the event marker between two groups
+    (about 2.5 us on the stream) is spread over per_group steps.  Seconds per step."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(groups + 1)]
+    torch.cuda.synchronize()
+    gc.disable()
+    try:
+        for g in range(groups):
+            ev[g].record()
+            for i in range(per_group):
+                fn(g * per_group + i)
+        ev[groups].record()
+        torch.cuda.synchronize()
+    finally:
+        gc.enable()
+    ts = [ev[g].elapsed_time(ev[g + 1]) * 1e-3 / per_group for g in range(groups)]
+    return statistics.median(ts), min(ts)
+
+
+def hbm_roofline(kernel, byts, mean_s, median_s, traffic_key=None, **extra):
+    ach = byts / mean_s / 1e9
+    r = {'bound': 'hbm', 'kernel': kernel, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+         'frac': round(ach / HBM_PEAK_GBS, 4), 'bytes_per_launch': byts, 'us_per_launch': round(mean_s * 1e6, 3),
+         'us_per_launch_median': round(median_s * 1e6, 3),
+         'frac_median': round(byts / median_s / 1e9 / HBM_PEAK_GBS, 4),
+         'traffic': load_traffic(traffic_key) if traffic_key else None}
+    if traffic_key:
+        r['traffic_source'] = TRAFFIC_SOURCE
+    r.update(extra)
+    return r
 
 
 def cpu_baseline_match(anchors_np, gt, lab, C, S, budget_s=6.0):
@@ -113,6 +224,30 @@ def cpu_baseline_nms(anchors_np, reg_np, sc_np, S, budget_s=4.0):
     return out
 
 
+def match_encode_case(lib, dev, stream, cfg, B, anchors, seed, sets):
+    """Device buffers + a step(i) closure of odbox_match_encode on BASELINE config `cfg` with batch B,
+    writing output set i % sets."""
+    c = workloads.CONFIGS[cfg]
+    S, C = c['S'], c['C']
+    N = anchors.shape[0]
+    gt_np, lab_np = workloads.match_inputs(cfg, batch=B, seed=seed)
+    gt = torch.as_tensor(gt_np).to(dev)
+    lab = torch.as_tensor(lab_np).to(dev)
+    G = gt.shape[1]
+    outs = [(torch.empty((B, N, 5), dtype=torch.float32, device=dev),
+             torch.empty((B, N, C + 1), dtype=torch.float32, device=dev)) for _ in range(sets)]
+
+    def step(i):
+        reg, labels = outs[i % sets]
+        rc = lib.odbox_match_encode(anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C,
+                                    float(S), float(S), 0.4, 0.5, reg.data_ptr(), labels.data_ptr(),
+                                    None, None, None, stream)
+        if rc:
+            _lib.check(rc, 'odbox_match_encode')
+    return step, dict(S=S, B=B, N=N, G=G, C=C, gt_np=gt_np, lab_np=lab_np, gt=gt, lab=lab, outs=outs,
+                      bytes=B * workloads.match_bytes_per_image(N, G, C))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -122,41 +257,41 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-nms', action='store_true')
     ap.add_argument('--no-loss', action='store_true')
+    ap.add_argument('--no-configs', action='store_true', help='skip the configs[0] / [2] / [3] sub-objects')
     ap.add_argument('--loss-steps', type=int, default=50)
+    ap.add_argument('--selftest-child', nargs='?', const='ok', default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    # ---- the launch contract, decided before anything touches the GPU ---------------------------
+    env_world = os.environ.get('WORLD_SIZE')
+    if args.gpus < 1:
+        print('bench.py: --gpus must be >= 1', file=sys.stderr)
+        return 2
+    if env_world is None and args.gpus > 1:
+        return spawn_ranks(args.gpus, sys.argv[1:])
+    if env_world is not None and int(env_world) != args.gpus:
+        print('bench.py: --gpus %d but WORLD_SIZE=%s: launch one rank per GPU (or let bench.py start them: '
+              'run it without torch.distributed.run)' % (args.gpus, env_world), file=sys.stderr)
+        return 2
+    if args.selftest_child:
+        return selftest_child(args)
+
     rank, world = oddist.init_from_env()
-    if world != args.gpus:
-        if rank == 0:
-            print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
     lib = _lib.load()
     dev = _lib.require_gpu()
     stream = _lib.stream_ptr()
 
     # ---------------- match + encode, configs[1] ------------------------------------------
-    cfg = workloads.CONFIGS[2]
-    S, B, G, C = cfg['S'], cfg['B'], cfg['G'], cfg['C']
-    anchors = yolo_grid_anchors(S)
-    N = anchors.shape[0]
-    assert N == workloads.num_anchors(2)
-    gt_np, lab_np = workloads.match_inputs(2, seed=1002 + 7919 * rank)
-    gt = torch.as_tensor(gt_np).to(dev)
-    lab = torch.as_tensor(lab_np).to(dev)
-    reg = torch.empty((B, N, 5), dtype=torch.float32, device=dev)
-    labels = torch.empty((B, N, C + 1), dtype=torch.float32, device=dev)
-
-    def step():
-        rc = lib.odbox_match_encode(anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C,
-                                    float(S), float(S), 0.4, 0.5, reg.data_ptr(), labels.data_ptr(),
-                                    None, None, None, stream)
-        if rc:
-            _lib.check(rc, 'odbox_match_encode')
-
+    anchors = yolo_grid_anchors(workloads.CONFIGS[2]['S'])
+    assert anchors.shape[0] == workloads.num_anchors(2)
+    step, w = match_encode_case(lib, dev, stream, 2, workloads.CONFIGS[2]['B'], anchors, 1002 + 7919 * rank, OUTPUT_SETS)
+    S, B, N, G, C = w['S'], w['B'], w['N'], w['G'], w['C']
     wall, ev = timed(step, args.steps, args.warmup, world)
+    med, _ = per_step_median(step)
     img_s = world * B * args.steps / wall
-    bytes_per_launch = B * workloads.match_bytes_per_image(N, G, C)
-    kernel_s = ev / args.steps
-    achieved = bytes_per_launch / kernel_s / 1e9
+    # the same launch rewriting ONE output set every step: its 245 MB fit the Infinity Cache
+    _, ev1 = timed(lambda i: step(0), args.steps, args.warmup, 1)
+    med1, _ = per_step_median(lambda i: step(0))
 
     result = {
         'metric': 'images/sec match+encode (IoU matching + target encoding)',
@@ -172,16 +307,56 @@ def main():
         'dtype': 'f32',
         'data': 'synthetic',
         'config': {'workload': 'configs[1]: YOLOv3-shaped 416x416 grid, 3 strides x 3 anchors = %d anchors, '
-                               '%d classes, %d GT boxes/img, batch %d per GPU, dense [B,N,5]+[B,N,C+1] outputs'
-                               % (N, C, G, B),
+                               '%d classes, %d GT boxes/img, batch %d per GPU, dense [B,N,5]+[B,N,C+1] outputs, '
+                               '%d output sets in rotation (%.2f GB) so that no step is absorbed by the Infinity Cache'
+                               % (N, C, G, B, OUTPUT_SETS, OUTPUT_SETS * B * N * (C + 6) * 4 / 1e9),
                    'global_batch': world * B, 'anchors': N, 'classes': C, 'gt_per_image': G,
                    'parallelism': 'images sharded over %d GPU(s), no collective' % world},
-        'roofline': {'bound': 'hbm', 'kernel': 'match_encode_kernel',
-                     'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': round(achieved / HBM_PEAK_GBS, 4),
-                     'bytes_per_launch': bytes_per_launch, 'us_per_launch': round(kernel_s * 1e6, 3),
-                     'traffic': load_traffic('match_encode_kernel')},
+        'roofline': hbm_roofline('match_encode_kernel', w['bytes'], ev / args.steps, med, 'match_encode_kernel_rotating',
+                                 output_sets=OUTPUT_SETS),
+        'roofline_cache_resident': hbm_roofline(
+            'match_encode_kernel', w['bytes'], ev1 / args.steps, med1, 'match_encode_kernel',
+            note='one output set rewritten every step: the 245 MB of stores fit the 256 MB Infinity Cache, so this is '
+                 'a cache-assisted store rate, not an HBM fraction'),
     }
+    gt_np, lab_np = w['gt_np'], w['lab_np']
+    gt, lab = w['gt'], w['lab']
+    del w, step
+
+    # ---------------- the same kernel on configs[0], configs[2] share, configs[3] ------------
+    if not args.no_configs:
+        ksteps = max(10, min(args.steps, 30))
+        retina512 = A.generate_anchors(A.AnchorsConfig(), 512)
+        for key, cfg, Bc, anch, sets, label in (
+                ('match_encode_cfg0', 1, 8, retina512, 8,
+                 'configs[0]: EfficientDet-D0 512x512, 49 104 anchors, 80 classes, 20 GT, batch 8; 8 output sets in rotation'),
+                ('match_encode_cfg2', 3, 32, None, 1,
+                 'configs[2] per-GPU share: 1024x1024, 196 416 anchors, 80 classes, 20 GT, batch 32 of 256 (2.26 GB per launch)'),
+                ('match_encode_cfg3', 4, 128, retina512, 2,
+                 'configs[3]: dense crowd, 500 GT boxes/img vs 49 104 anchors, 1 class, batch 128')):
+            if anch is None:
+                anch = A.generate_anchors(A.AnchorsConfig(), workloads.CONFIGS[cfg]['S'])
+            stepc, wc = match_encode_case(lib, dev, stream, cfg, Bc, anch, 1000 + cfg + 7919 * rank, sets)
+            wl, el = timed(stepc, ksteps, 3, world)
+            medc, _ = per_step_median(stepc, per_group=5)
+            sub = {'value': round(world * Bc * ksteps / wl, 1), 'unit': 'images/s', 'steps': ksteps,
+                   'config': {'workload': label}}
+            if cfg == 4:
+                # VALU-bound: 500 GT rows per anchor.  The kernel proves most pairs zero without
+                # evaluating them, so "pairs / peak rate" is not a fraction of anything; the defensible figure is
+                # how busy the VALUs are over the launch (SQ counters, collected in their own PMC passes).
+                sub['roofline'] = {'bound': 'valu', 'kernel': 'match_encode_kernel', 'us_per_launch': round(el / ksteps * 1e6, 2),
+                                   'us_per_launch_median': round(medc * 1e6, 2),
+                                   'bytes_per_launch': wc['bytes'],
+                                   'hbm_frac': round(wc['bytes'] / (el / ksteps) / 1e9 / HBM_PEAK_GBS, 4),
+                                   'frac': load_static('match_encode_cfg3_valu_busy'),
+                                   'frac_source': 'static: VALU-busy cycles / launch cycles from the SQ counter passes '
+                                                  '(tools/pmc_cfg.sh 4, profiles/), not measured in this run'}
+            else:
+                sub['roofline'] = hbm_roofline('match_encode_kernel', wc['bytes'], el / ksteps, medc, None, output_sets=sets)
+            result[key] = sub
+            del stepc, wc
+        torch.cuda.empty_cache()
 
     # ---------------- fused matcher + loss on the same batch ----------
     if not args.no_loss:
@@ -192,54 +367,44 @@ def main():
         gb, gs = torch.empty_like(pb), torch.empty_like(ps)
         ws = torch.empty(lib.odbox_match_loss_workspace(B, N), dtype=torch.uint8, device=dev)
         result['match_loss'] = {}
-        for name, g1, g2 in (('forward', None, None), ('forward_backward', gb, gs)):
-            def loss_step():
-                rc = lib.odbox_match_loss(anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C, float(S),
-                                          float(S), 0.4, 0.5, pb.data_ptr(), ps.data_ptr(), 1.5, 0.25, 1.0,
-                                          out4.data_ptr(), None if g1 is None else g1.data_ptr(),
-                                          None if g2 is None else g2.data_ptr(), ws.data_ptr(), ws.numel(), stream)
-                if rc:
-                    _lib.check(rc, 'odbox_match_loss')
-            wl, el = timed(loss_step, args.loss_steps, 5, world)
-            byt = B * (N * (32 + 4 * C) + 20 * G) * (1 if g1 is None else 2)   # anchors + predictions (+ gradients)
-            ach = byt / (el / args.loss_steps) / 1e9
-            result['match_loss'][name] = {
-                'value': round(world * B * args.loss_steps / wl, 1), 'unit': 'images/s',
-                'us_per_step': round(el / args.loss_steps * 1e6, 2), 'steps': args.loss_steps,
-                'roofline': {'bound': 'hbm', 'kernel': 'match_loss_kernel + loss_reduce_kernel', 'achieved': round(ach, 1),
-                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                             'bytes_per_launch': byt,
-                             'traffic': load_traffic('match_loss_kernel_fwd' if g1 is None else 'match_loss_kernel_fwd_bwd')}}
-        # the autograd backward launch (gradients only, scaled on the device) and the fp16 variants
+        common = (anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C, float(S), float(S), 0.4, 0.5)
         scale2 = torch.tensor([0.5, 0.25], device=dev)
         hb, hs = pb.half(), ps.half()
         ghb, ghs = torch.empty_like(hb), torch.empty_like(hs)
-        common = (anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C, float(S), float(S), 0.4, 0.5)
 
-        def bwd_step():
+        def fwd_step(i):
+            _lib.check(lib.odbox_match_loss(*common, pb.data_ptr(), ps.data_ptr(), 1.5, 0.25, 1.0, out4.data_ptr(), None, None,
+                                            ws.data_ptr(), ws.numel(), stream), 'forward')
+
+        def fwd_bwd_step(i):
+            _lib.check(lib.odbox_match_loss(*common, pb.data_ptr(), ps.data_ptr(), 1.5, 0.25, 1.0, out4.data_ptr(), gb.data_ptr(),
+                                            gs.data_ptr(), ws.data_ptr(), ws.numel(), stream), 'forward_backward')
+
+        def bwd_step(i):
             _lib.check(lib.odbox_match_loss_backward(*common, pb.data_ptr(), ps.data_ptr(), 1.5, 0.25, 1.0,
                                                      scale2[0:1].data_ptr(), scale2[1:2].data_ptr(), out4[2:3].data_ptr(), gb.data_ptr(), gs.data_ptr(), stream), 'backward')
 
-        def fwd16_step():
+        def fwd16_step(i):
             _lib.check(lib.odbox_match_loss_f16(*common, hb.data_ptr(), hs.data_ptr(), 1.5, 0.25, 1.0, out4.data_ptr(),
                                                 None, None, ws.data_ptr(), ws.numel(), stream), 'forward_f16')
 
-        def bwd16_step():
+        def bwd16_step(i):
             _lib.check(lib.odbox_match_loss_backward_f16(*common, hb.data_ptr(), hs.data_ptr(), 1.5, 0.25, 1.0,
                                                          scale2[0:1].data_ptr(), scale2[1:2].data_ptr(), out4[2:3].data_ptr(), ghb.data_ptr(), ghs.data_ptr(), stream),
                        'backward_f16')
         fixed = B * (N * 16 + 20 * G)                                          # anchors + ground truth, always fp32
-        for name, fn, byt in (('backward', bwd_step, fixed + 2 * B * N * (16 + 4 * C)),
-                              ('forward_f16', fwd16_step, fixed + B * N * (8 + 2 * C)),
-                              ('backward_f16', bwd16_step, fixed + 2 * B * N * (8 + 2 * C))):
+        full = B * (N * (32 + 4 * C) + 20 * G)                                 # anchors + predictions
+        for name, fn, byt, tkey in (('forward', fwd_step, full, 'match_loss_kernel_fwd'),
+                                    ('forward_backward', fwd_bwd_step, 2 * full, 'match_loss_kernel_fwd_bwd'),
+                                    ('backward', bwd_step, fixed + 2 * B * N * (16 + 4 * C), None),
+                                    ('forward_f16', fwd16_step, fixed + B * N * (8 + 2 * C), 'match_loss_kernel_f16_fwd'),
+                                    ('backward_f16', bwd16_step, fixed + 2 * B * N * (8 + 2 * C), 'match_loss_kernel_f16_bwd')):
             wl, el = timed(fn, args.loss_steps, 5, world)
-            ach = byt / (el / args.loss_steps) / 1e9
+            medl, _ = per_step_median(fn)
             result['match_loss'][name] = {
                 'value': round(world * B * args.loss_steps / wl, 1), 'unit': 'images/s',
                 'us_per_step': round(el / args.loss_steps * 1e6, 2), 'steps': args.loss_steps,
-                'roofline': {'bound': 'hbm', 'kernel': 'match_loss_kernel', 'achieved': round(ach, 1),
-                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                             'bytes_per_launch': byt, 'traffic': None}}
+                'roofline': hbm_roofline('match_loss_kernel (+ its reduction)', byt, el / args.loss_steps, medl, tkey)}
         del pb, ps, gb, gs, hb, hs, ghb, ghs
 
     # ---------------- decode + NMS, configs[4] per-GPU share -------------------------------
@@ -248,7 +413,7 @@ def main():
         anchors5 = A.generate_anchors(A.AnchorsConfig(), S5)
         N5 = anchors5.shape[0]
         reg5_np, sc5_np = workloads.nms_inputs(N5, C=C5, batch=B5, seed=1005 + 7919 * rank,
-                                               p3p4_anchors=9 * (64 * 64 + 32 * 32))
+                                               p3p4_anchors=9 * (64 * 64 + 32 * 32), distinct=B5)
         reg5 = torch.as_tensor(reg5_np).to(dev)
         sc5 = torch.as_tensor(sc5_np).to(dev)
         cb5 = None
@@ -257,23 +422,22 @@ def main():
         del reg5_np, sc5_np
         out = {}
 
-        def nms_step():
+        def nms_step(i):
             b, s, l = BB.decode_and_nms(anchors5, reg5, sc5, (S5, S5))
             out['det'] = oddist.gather_detections(b, s, l, batch=None)
 
         wall5, ev5 = timed(nms_step, args.nms_steps, 3, world)
+        med5, _ = per_step_median(nms_step, per_group=4)
         bytes5 = B5 * workloads.nms_bytes_per_image(N5, C5)
-        ach5 = bytes5 / (ev5 / args.nms_steps) / 1e9
         result['decode_nms'] = {
             'metric': 'images/sec decode+clip+per-class NMS+top-k' + (' + RCCL all-gather' if world > 1 else ''),
             'value': round(world * B5 * args.nms_steps / wall5, 1), 'unit': 'images/s',
             'ms_per_step': round(wall5 / args.nms_steps * 1e3, 4), 'steps': args.nms_steps,
-            'config': {'workload': 'configs[4] per-GPU share: %d anchors, %d classes, batch %d per GPU, '
-                                   'score 0.3, IoU 0.45, max_ret 100, ~4500 candidates/img' % (N5, C5, B5)},
-            'roofline': {'bound': 'hbm', 'kernel': 'whole decode+NMS pipeline (score_scan dominates)',
-                         'achieved': round(ach5, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(ach5 / HBM_PEAK_GBS, 4), 'bytes_per_launch': bytes5,
-                         'traffic': load_traffic('score_scan_kernel')},
+            'config': {'workload': 'configs[4] per-GPU share: %d anchors, %d classes, batch %d per GPU (%d distinct synthetic '
+                                   'images), score 0.3, IoU 0.45, max_ret 100, ~4500 candidates/img; the 1.13 GB score '
+                                   'tensor is 4x the Infinity Cache' % (N5, C5, B5, B5)},
+            'roofline': hbm_roofline('whole decode+NMS pipeline (score_scan dominates)', bytes5, ev5 / args.nms_steps, med5,
+                                     'score_scan_kernel'),
             'detections_per_image_mean': float((out['det'][1] > 0).sum().item()) / (world * B5),
         }
         if cb5 is not None:
@@ -301,18 +465,25 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
-def load_traffic(kernel):
-    """HBM bytes per launch from the PMC passes (profiles/pmc_traffic.json, written from the
-    rocprofv3 --pmc runs of profiles/README.md); null until collected."""
+def load_static(key, field=None):
+    """A figure from the PMC passes (profiles/pmc_traffic.json, written from the rocprofv3 --pmc runs of
+    profiles/README.md); null until collected."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     try:
         with open(path) as f:
-            return json.load(f).get(kernel, {}).get('hbm_bytes_per_launch')
+            v = json.load(f).get(key)
+        return v.get(field) if field and isinstance(v, dict) else v
     except (OSError, ValueError):
         return None
 
 
+def load_traffic(kernel):
+    """HBM bytes per launch (TCC FETCH_SIZE x 2 for gfx950's wide reads + WRITE_SIZE)."""
+    return load_static(kernel, 'hbm_bytes_per_launch')
+
+
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -254,9 +254,11 @@ int odbox_coco_match(const float *dt_boxes /*[B,R,4]*/, const float *dt_scores /
  * (square pad), 4 corners, each coordinate / max(H,W) * image_size, optional round to fp16
  * (half_round != 0: the mixed-precision input pipeline), polygon2bbox (:77-95), rows beyond
  * max_items cut, missing rows = -1 boxes / -1 labels.  mode 0 = (xmin,ymin,xmax,ymax),
- * 1 = want_yx, 2 = want_wh.  orig_hw [B,2] = (height, width) of the original image as floats. */
+ * 1 = want_yx, 2 = want_wh.  orig_hw [B,2] = (height, width) of the original image as floats.
+ * rows = length of boxes_xywh / labels (both may be NULL when it is 0); the offsets are read on the
+ * device and clamped into [0, rows], so a bad table gives wrong rows, never a fault. */
 int odbox_gt_prepare_xywh(const float *boxes_xywh /*[rows,4]*/, const int32_t *labels /*[rows]*/,
-                          const int32_t *row_offsets /*[B+1]*/, const float *orig_hw /*[B,2]*/, int B,
+                          const int32_t *row_offsets /*[B+1]*/, int rows, const float *orig_hw /*[B,2]*/, int B,
                           int max_items, float image_size, int half_round, int mode,
                           float *out_boxes /*[B,max_items,4]*/, int32_t *out_labels /*[B,max_items]*/,
                           void *stream);
@@ -264,7 +266,7 @@ int odbox_gt_prepare_xywh(const float *boxes_xywh /*[rows,4]*/, const int32_t *l
 /* The same from corner polygons [rows,4,2] on a square canvas of side canvas_size[b] (what the
  * training augmentation hands back, detection.py:126,131-141). */
 int odbox_gt_prepare_poly(const float *polys /*[rows,4,2]*/, const int32_t *labels /*[rows]*/,
-                          const int32_t *row_offsets /*[B+1]*/, const float *canvas_size /*[B]*/, int B,
+                          const int32_t *row_offsets /*[B+1]*/, int rows, const float *canvas_size /*[B]*/, int B,
                           int max_items, float image_size, int half_round, int mode,
                           float *out_boxes /*[B,max_items,4]*/, int32_t *out_labels /*[B,max_items]*/,
                           void *stream);

@@ -2,6 +2,7 @@
 library is missing or no GPU is present every compute entry raises."""
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -56,8 +57,8 @@ SIGNATURES = {
     'odbox_pack_records': (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     'odbox_unpack_records': (_i, [_vp, _sz, _vp, _vp, _vp, _vp]),
     'odbox_restore_boxes': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
-    'odbox_gt_prepare_xywh': (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp]),
-    'odbox_gt_prepare_poly': (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp]),
+    'odbox_gt_prepare_xywh': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp]),
+    'odbox_gt_prepare_poly': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp]),
 }
 
 
@@ -100,6 +101,28 @@ def stream_ptr():
 
 def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+_ws_lock = threading.Lock()
+_ws_cache = {}
+
+
+def workspace(kind, dev, need):
+    """Scratch bytes for one library call: one buffer per (kind, device, stream, host thread), grown
+    on demand and reused by later calls.  Two host threads never share a buffer (calls that overlap
+    must not share a workspace, include/odbox.h), and calls of one thread on one stream are ordered
+    by the stream.  `release_workspaces()` drops them all."""
+    key = (kind, dev, torch.cuda.current_stream().cuda_stream, threading.get_ident())
+    with _ws_lock:
+        ws = _ws_cache.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _ws_cache[key] = torch.empty(max(int(need), 256), dtype=torch.uint8, device=dev)
+        return ws
+
+
+def release_workspaces():
+    with _ws_lock:
+        _ws_cache.clear()
 
 
 def as_dev(x, dtype, device):

@@ -10,9 +10,6 @@ import torch
 
 from . import _lib
 
-_ws_cache = {}
-
-
 def _boxes2(boxes, dev):
     boxes = _lib.as_dev(boxes, torch.float32, dev)
     if boxes.dim() != 2 or boxes.shape[1] != 4:
@@ -102,11 +99,7 @@ def _workspace(lib, dev, B, N, C, max_ret, topk):
     if need == 0:
         raise _lib.OdboxError('odbox_decode_nms_workspace: unsupported sizes B=%d N=%d C=%d max_ret=%d'
                               % (B, N, C, max_ret))
-    key = (dev, torch.cuda.current_stream().cuda_stream)
-    ws = _ws_cache.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _ws_cache[key] = torch.empty(need, dtype=torch.uint8, device=dev)
-    return ws
+    return _lib.workspace('decode_nms', dev, need)
 
 
 def _decode_nms(anchors, regress_or_boxes, class_scores, im_size, do_clip,

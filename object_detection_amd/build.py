@@ -44,6 +44,35 @@ def needs_build():
     return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
 
 
+def check_m0(hipcc, hooks, verbose=False):
+    """odbox_infer.hip sets M0 from inline asm for its LDS-DMA loads (s_mov_b32 m0 + global_load_lds in
+    ONE asm statement).  M0 is a reserved register that hipcc refuses in a clobber list, so the
+    assumption "the compiler keeps nothing of its own in M0 across those statements" is verified on
+    the generated code instead: in the device assembly of that unit every instruction that names m0
+    must be one of those s_mov_b32, directly followed by its s_nop and its global_load_lds."""
+    unit = 'odbox_infer.hip'
+    asm = os.path.join(OBJ, 'odbox_infer.s')
+    cmd = [hipcc] + COMMON + UNITS[unit] + hooks + ['-S', '--cuda-device-only', '-Wno-unused-command-line-argument',
+                                                    os.path.join(CSRC, unit), '-o', asm]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, check=True)
+    lines = [l.split(';')[0].strip() for l in open(asm)]
+    lines = [l for l in lines if l and not l.startswith(('.', '//'))]
+    sets = 0
+    for i, l in enumerate(lines):
+        if 'm0' not in l.replace(',', ' ').split():
+            continue
+        ok = (l.startswith('s_mov_b32 m0,') and i + 2 < len(lines) and lines[i + 1].startswith('s_nop')
+              and lines[i + 2].startswith('global_load_lds_dword'))
+        if not ok:
+            raise RuntimeError('%s: an instruction outside the LDS-DMA asm statements uses m0: %r (see dma16 / dma4)' % (asm, l))
+        sets += 1
+    if sets == 0:
+        raise RuntimeError('%s: no LDS-DMA found -- the check is looking at the wrong file' % asm)
+    return sets
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
@@ -58,6 +87,7 @@ def build(force=False, verbose=False):
             print(' '.join(cmd))
         subprocess.run(cmd, check=True)
         objs.append(obj)
+    check_m0(hipcc, hooks, verbose)
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
     if verbose:
         print(' '.join(cmd))

@@ -18,8 +18,6 @@ import torch
 
 from . import _lib
 
-_ws_cache = {}
-
 
 class Params:
     """cocoeval.py:506-515 (bbox parameters)."""
@@ -103,10 +101,7 @@ def evaluate_img(dt_boxes, dt_scores, dt_labels, gt_boxes, gt_labels, num_classe
                gt_ignore=torch.empty((B, A, G), dtype=torch.uint8, device=dev),
                dt_rank=torch.empty((B, R), dtype=torch.int32, device=dev))
     need = lib.odbox_coco_match_workspace(B, R)
-    key = (dev, torch.cuda.current_stream().cuda_stream)
-    ws = _ws_cache.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _ws_cache[key] = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+    ws = _lib.workspace('coco_match', dev, need)
     _lib.check(lib.odbox_coco_match(
         _lib.ptr(dt_boxes), _lib.ptr(dt_scores), _lib.ptr(dt_labels), _lib.ptr(gt_boxes), _lib.ptr(gt_labels),
         B, R, G, int(num_classes), thr.ctypes.data_as(ctypes.c_void_p), T, rng.ctypes.data_as(ctypes.c_void_p), A,

@@ -393,7 +393,7 @@ __device__ __forceinline__ float4 poly_bbox(const float px[4], const float py[4]
 // training augmentation, detection.py:126,131).
 template <bool FROM_XYWH, bool HALF>
 __global__ __launch_bounds__(256) void gt_prepare_kernel(const float *__restrict__ src, const int32_t *__restrict__ labels,
-                                                         const int32_t *__restrict__ row_offsets,
+                                                         const int32_t *__restrict__ row_offsets, int rows,
                                                          const float *__restrict__ sizes, int B, int max_items,
                                                          float image_size, int mode, float4 *__restrict__ out_boxes,
                                                          int32_t *__restrict__ out_labels)
@@ -401,7 +401,9 @@ __global__ __launch_bounds__(256) void gt_prepare_kernel(const float *__restrict
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= (uint32_t)B * (uint32_t)max_items) return;
     const uint32_t b = i / (uint32_t)max_items, k = i - b * (uint32_t)max_items;
-    const int32_t r0 = row_offsets[b], r1 = row_offsets[b + 1];
+    // offsets come from device memory: clamped into [0, rows] so that a corrupted table gives wrong
+    // rows, never an access outside the two ragged arrays
+    const int32_t r0 = min(max(row_offsets[b], 0), rows), r1 = min(max(row_offsets[b + 1], r0), rows);
     float4 box = make_float4(-1.f, -1.f, -1.f, -1.f);                    // padding_values -1 (:262)
     int32_t lab = -1;
     if ((int32_t)k < r1 - r0) {                                           // rows past max_items are cut (:140-141)
@@ -441,12 +443,13 @@ __global__ __launch_bounds__(256) void gt_prepare_kernel(const float *__restrict
 }
 
 int gt_prepare(const char *name, bool from_xywh, const float *src, const int32_t *labels, const int32_t *row_offsets,
-               const float *sizes, int B, int max_items, float image_size, int half_round, int mode, float *out_boxes,
+               int rows, const float *sizes, int B, int max_items, float image_size, int half_round, int mode, float *out_boxes,
                int32_t *out_labels, void *stream)
 {
-    if (B < 0 || max_items < 0) return fail(ODBOX_EINVAL, "%s: negative shape", name);
+    if (B < 0 || max_items < 0 || rows < 0) return fail(ODBOX_EINVAL, "%s: negative shape", name);
     if (B == 0 || max_items == 0) return 0;
     if (!row_offsets || !sizes || !out_boxes || !out_labels) return fail(ODBOX_EINVAL, "%s: NULL pointer", name);
+    if (rows > 0 && (!src || !labels)) return fail(ODBOX_EINVAL, "%s: NULL boxes / labels with rows = %d", name, rows);
     if (mode < 0 || mode > 2) return fail(ODBOX_EINVAL, "%s: mode must be 0 (xyxy), 1 (yxyx) or 2 (xywh)", name);
     if ((src && !aligned16(src)) || !aligned16(out_boxes))
         return fail(ODBOX_EINVAL, "%s: box tensors must be 16-byte aligned", name);
@@ -456,7 +459,7 @@ int gt_prepare(const char *name, bool from_xywh, const float *src, const int32_t
     const dim3 grid((uint32_t)((total + 255) / 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
     auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, grid, block, 0, st, src, labels, row_offsets, sizes, B, max_items, image_size, mode,
+        hipLaunchKernelGGL(kernel, grid, block, 0, st, src, labels, row_offsets, rows, sizes, B, max_items, image_size, mode,
                            (float4 *)out_boxes, out_labels);
     };
     if (from_xywh) { if (half_round) launch(gt_prepare_kernel<true, true>); else launch(gt_prepare_kernel<true, false>); }
@@ -536,19 +539,19 @@ __global__ __launch_bounds__(256) void unpack_records_kernel(const float *__rest
 
 extern "C" {
 
-int odbox_gt_prepare_xywh(const float *boxes_xywh, const int32_t *labels, const int32_t *row_offsets,
+int odbox_gt_prepare_xywh(const float *boxes_xywh, const int32_t *labels, const int32_t *row_offsets, int rows,
                           const float *orig_hw, int B, int max_items, float image_size, int half_round, int mode,
                           float *out_boxes, int32_t *out_labels, void *stream)
 {
-    return gt_prepare("odbox_gt_prepare_xywh", true, boxes_xywh, labels, row_offsets, orig_hw, B, max_items, image_size,
+    return gt_prepare("odbox_gt_prepare_xywh", true, boxes_xywh, labels, row_offsets, rows, orig_hw, B, max_items, image_size,
                       half_round, mode, out_boxes, out_labels, stream);
 }
 
-int odbox_gt_prepare_poly(const float *polys, const int32_t *labels, const int32_t *row_offsets, const float *canvas_size,
-                          int B, int max_items, float image_size, int half_round, int mode, float *out_boxes,
+int odbox_gt_prepare_poly(const float *polys, const int32_t *labels, const int32_t *row_offsets, int rows,
+                          const float *canvas_size, int B, int max_items, float image_size, int half_round, int mode, float *out_boxes,
                           int32_t *out_labels, void *stream)
 {
-    return gt_prepare("odbox_gt_prepare_poly", false, polys, labels, row_offsets, canvas_size, B, max_items, image_size,
+    return gt_prepare("odbox_gt_prepare_poly", false, polys, labels, row_offsets, rows, canvas_size, B, max_items, image_size,
                       half_round, mode, out_boxes, out_labels, stream);
 }
 

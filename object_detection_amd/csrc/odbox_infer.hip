@@ -8,6 +8,9 @@
 //
 // Reference citations are file:line under the reference tree (bioothod/object_detection).
 #include "odbox_common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 
 using namespace odbox;
 
@@ -42,8 +45,11 @@ struct ScanGeom {
 // ds_read as dependent on every outstanding DMA and puts s_waitcnt vmcnt(0) in front of it,
 // which would serialise the prefetch of tile i+1 with the reduce of tile i.  Here the waits are
 // ours: one s_waitcnt vmcnt(0) before a buffer is read.  M0 = wave-uniform LDS byte address;
-// lane l lands at M0 + l * size.  (M0 is a reserved register; nothing else in these kernels
-// uses it.  s_nop covers the SALU-writes-M0 -> LDS-DMA hazard.)
+// lane l lands at M0 + l * size.  M0 is written and consumed inside ONE asm statement, so nothing
+// is scheduled between the two instructions.  M0 is a reserved register (hipcc rejects it in a
+// clobber list), so that the compiler keeps no value of its own in it across the statement is
+// CHECKED instead: build.py disassembles this unit and fails the build if any instruction other
+// than these s_mov_b32 names m0 (check_m0).  s_nop covers the SALU-writes-M0 -> LDS-DMA hazard.
 // `stream` (wave-uniform): the `nt` cache policy -- a score tensor far beyond the 256 MB Infinity
 // Cache is read once and should not be kept anywhere (config 5: 192 -> 176 us); a small one may
 // still sit in that cache from its producer, where nt loads were measured slower (loss kernel).
@@ -1277,12 +1283,26 @@ int device_cu_count()
 }
 
 // dynamic LDS above the 64 KiB default needs an explicit opt-in per kernel
+// (the attribute is a maximum and sticks to the function on that device: asked once per (device,
+// kernel) and size, not on every call -- it was up to four runtime calls on the hot host path)
+int allow_lds_impl(const void *kernel, size_t bytes)
+{
+    if (bytes <= 48 * 1024) return 0;
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, size_t> granted;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &have = granted[std::make_pair(dev, kernel)];
+    if (have >= bytes) return 0;
+    HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    have = bytes;
+    return 0;
+}
 template <typename K>
 int allow_lds(K kernel, size_t bytes)
 {
-    if (bytes <= 48 * 1024) return 0;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return 0;
+    return allow_lds_impl(reinterpret_cast<const void *>(kernel), bytes);
 }
 
 template <int V, int LL>

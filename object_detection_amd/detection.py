@@ -38,7 +38,7 @@ def _launch(entry, src, lab, offs, sz, B, image_size, max_items, dtype, want_yx,
     out_l = torch.empty((B, max_items), dtype=torch.int32, device=dev)
     mode = 1 if want_yx else (2 if want_wh else 0)
     fn = getattr(lib, entry)
-    _lib.check(fn(_lib.ptr(src), _lib.ptr(lab), _lib.ptr(offs), _lib.ptr(sz), B, int(max_items), float(image_size),
+    _lib.check(fn(_lib.ptr(src), _lib.ptr(lab), _lib.ptr(offs), int(lab.shape[0]), _lib.ptr(sz), B, int(max_items), float(image_size),
                   1 if dtype == torch.float16 else 0, mode, _lib.ptr(out_b), _lib.ptr(out_l), _lib.stream_ptr()), entry)
     return (out_b.to(dtype) if dtype != torch.float32 else out_b), out_l
 

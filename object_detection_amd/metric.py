@@ -15,15 +15,8 @@ import torch
 from . import _lib
 from .anchors import _image_hw
 
-_ws_cache = {}
-
-
 def _workspace(dev, need):
-    key = (dev, torch.cuda.current_stream().cuda_stream)
-    ws = _ws_cache.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _ws_cache[key] = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
-    return ws
+    return _lib.workspace('loss', dev, need)
 
 
 def _focal_launch(lib, y_true, y_pred, gamma, alpha, want_grad):

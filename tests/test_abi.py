@@ -182,13 +182,15 @@ def test_every_entry_rejects_bad_arguments_without_touching_the_gpu(lib):
         ('odbox_coco_match', (p, p, p, p, p, 1, 2, 2, 3, thr, 2, rng, 1, 100, p, p, None, None, p, p, 4, None), -3),
         ('odbox_coco_match', (p, p, p, p, p, 1, 2, 2, 3, thr, 99, rng, 1, 100, p, p, None, None, p, p, 1 << 20, None), -1),     # too many thresholds
         ('odbox_coco_match', (p, p, p, p, p, 1, 2, 5000, 3, thr, 2, rng, 1, 100, p, p, None, None, p, p, 1 << 20, None), -1),   # G over the limit
-        ('odbox_gt_prepare_xywh', (p, p, None, p, 2, 4, 512.0, 0, 0, p, p, None), -1),
+        ('odbox_gt_prepare_xywh', (p, p, None, 8, p, 2, 4, 512.0, 0, 0, p, p, None), -1),
+        ('odbox_gt_prepare_xywh', (p, None, p, 8, p, 2, 4, 512.0, 0, 0, p, p, None), -1),                                          # labels NULL with rows > 0
+        ('odbox_gt_prepare_poly', (None, p, p, 8, p, 2, 4, 512.0, 0, 0, p, p, None), -1),                                          # polygons NULL with rows > 0
         ('odbox_restore_boxes', (p, p, None, 2, 4, 512, p, p, None), -1),
         ('odbox_pack_records', (p, p, None, 8, p, None), -1),
         ('odbox_unpack_records', (p, 8, odd, p, p, None), -1),
         ('odbox_restore_boxes', (p, p, p, 2, 4, 0, p, p, None), -1),                                                             # image_size
-        ('odbox_gt_prepare_poly', (p, p, p, p, 2, 4, 512.0, 0, 7, p, p, None), -1),                                              # mode
-        ('odbox_gt_prepare_xywh', (p, p, p, p, 2, 4, 0.0, 0, 0, p, p, None), -1),                                                # image_size
+        ('odbox_gt_prepare_poly', (p, p, p, 8, p, 2, 4, 512.0, 0, 7, p, p, None), -1),                                              # mode
+        ('odbox_gt_prepare_xywh', (p, p, p, 8, p, 2, 4, 0.0, 0, 0, p, p, None), -1),                                                # image_size
     ]
     for name, args, want in cases:
         rc = getattr(lib, name)(*args)
@@ -199,4 +201,4 @@ def test_every_entry_rejects_bad_arguments_without_touching_the_gpu(lib):
     assert lib.odbox_clip_boxes(None, 0, 8.0, 8.0, None, None) == 0
     assert lib.odbox_decode_nms(None, None, None, 0, 4, 2, 8.0, 8.0, 1, 0.3, 0.45, 100, 0, None, None, None, None, None, None, 0, None) == 0
     assert lib.odbox_coco_match(None, None, None, None, None, 0, 2, 2, 3, thr, 2, rng, 1, 100, None, None, None, None, None, None, 0, None) == 0
-    assert lib.odbox_gt_prepare_xywh(None, None, None, None, 0, 4, 512.0, 0, 0, None, None, None) == 0
+    assert lib.odbox_gt_prepare_xywh(None, None, None, 0, None, 0, 4, 512.0, 0, 0, None, None, None) == 0

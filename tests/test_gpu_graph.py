@@ -128,7 +128,7 @@ def test_loss_eval_and_gt_preparation_replay_from_a_hip_graph():
                                   dtm.data_ptr(), dti.data_ptr(), gtm.data_ptr(), gti.data_ptr(), rank.data_ptr(),
                                   ws_ev.data_ptr(), ws_ev.numel(), st)
         assert rc == 0, lib.odbox_last_error()
-        rc = lib.odbox_gt_prepare_xywh(t['xywh'].data_ptr(), t['xl'].data_ptr(), offs.data_ptr(), hw.data_ptr(), B, 64, 512.0,
+        rc = lib.odbox_gt_prepare_xywh(t['xywh'].data_ptr(), t['xl'].data_ptr(), offs.data_ptr(), int(t['xl'].shape[0]), hw.data_ptr(), B, 64, 512.0,
                                        0, 0, pb_out.data_ptr(), pl_out.data_ptr(), st)
         assert rc == 0, lib.odbox_last_error()
         rc = lib.odbox_match_loss_backward(anchors.data_ptr(), t['gt'].data_ptr(), t['lab'].data_ptr(), B, N, Gp, C, float(S),

@@ -101,3 +101,26 @@ def test_bad_arguments():
         D.prepare_batch([np.zeros((2, 4))], [np.zeros(3)], [(10, 10)], 512)
     with pytest.raises(ValueError):
         D.prepare_batch([np.zeros((2, 4))], [np.zeros(2)], [(10, 10)], 512, dtype=torch.float64)
+
+
+def test_corrupted_row_offsets_give_wrong_rows_never_a_fault():
+    """The offsets table is read on the device: values outside [0, rows] are clamped there (include/odbox.h)."""
+    from object_detection_amd import _lib
+    lib = _lib.load()
+    dev = _lib.require_gpu()
+    rows, B, M = 10, 4, 8
+    xywh = torch.rand((rows, 4), device=dev) * 50 + 1
+    lab = torch.arange(rows, dtype=torch.int32, device=dev)
+    hw = torch.full((B, 2), 100.0, device=dev)
+    ob = torch.empty((B, M, 4), device=dev)
+    ol = torch.empty((B, M), dtype=torch.int32, device=dev)
+    offs = torch.tensor([-5, 3, 1 << 30, -(1 << 30), 7], dtype=torch.int32, device=dev)
+    rc = lib.odbox_gt_prepare_xywh(xywh.data_ptr(), lab.data_ptr(), offs.data_ptr(), rows, hw.data_ptr(), B, M, 64.0, 0, 0,
+                                   ob.data_ptr(), ol.data_ptr(), _lib.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = ol.cpu().numpy()
+    np.testing.assert_array_equal(got[0], [0, 1, 2, -1, -1, -1, -1, -1])       # [-5, 3) -> [0, 3)
+    np.testing.assert_array_equal(got[1], [3, 4, 5, 6, 7, 8, 9, -1])           # [3, 2^30) -> [3, 10)
+    assert (got[2] == -1).all()                                                # [2^30, -2^30) -> [10, 10): empty
+    np.testing.assert_array_equal(got[3], [0, 1, 2, 3, 4, 5, 6, -1])           # [-2^30, 7) -> [0, 7)

@@ -241,7 +241,7 @@ def main():
         ol = torch.empty((B, max_items), dtype=torch.int32, device=dev)
 
         def step():
-            rc = lib.odbox_gt_prepare_xywh(d_boxes.data_ptr(), d_lab.data_ptr(), d_offs.data_ptr(), d_hw.data_ptr(), B, max_items,
+            rc = lib.odbox_gt_prepare_xywh(d_boxes.data_ptr(), d_lab.data_ptr(), d_offs.data_ptr(), int(d_lab.shape[0]), d_hw.data_ptr(), B, max_items,
                                            float(S), 0, 0, ob.data_ptr(), ol.data_ptr(), st)
             assert rc == 0
         t = event_time(step, args.iters)

@@ -48,9 +48,57 @@ __global__ __launch_bounds__(256) void fill_block_chunk_asm(v4f *p, uint32_t per
         }
 }
 
-template <typename F>
-static float timed(F launch, hipStream_t st)
+static int g_iter = 0;      // launch counter: the experiments write buffer g_iter % sets
+// E: tile chunks with the number of resident blocks per CU limited by dynamic LDS (window of tiles being written)
+__global__ __launch_bounds__(256) void fill_block_chunk_occ(v4f *p, uint32_t per_block, size_t nvec)
 {
+    extern __shared__ float dyn[];
+    if (per_block == 0xffffffffu) dyn[threadIdx.x] = 0.f;
+    const size_t base = (size_t)blockIdx.x * per_block;
+    const v4f z = {0, 0, 0, 0};
+    for (uint32_t v = threadIdx.x; v < per_block; v += 256)
+        if (base + v < nvec) p[base + v] = z;
+}
+// F: persistent blocks striding over tiles: block k writes tiles k, k + grid, ...
+template <bool NT>
+__global__ __launch_bounds__(256) void fill_tiles_persistent(v4f *p, uint32_t per_block, uint32_t tiles, size_t nvec)
+{
+    const v4f z = {0, 0, 0, 0};
+    for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const size_t base = (size_t)t * per_block;
+        for (uint32_t v = threadIdx.x; v < per_block; v += 256)
+            if (base + v < nvec) {
+                if (NT) __builtin_nontemporal_store(z, p + base + v);
+                else p[base + v] = z;
+            }
+    }
+}
+
+// G: grid-stride sweep whose blocks lose lockstep: MODE 0 = every `period` pieces the block burns `burn` clocks
+// (a stand-in for the match of one tile), MODE 1 = the same with a per-(block, step) pseudo-random length,
+// MODE 2 = no burn, but XCD x owns a contiguous eighth of every grid-wide row instead of every 8th piece
+template <int MODE>
+__global__ __launch_bounds__(256) void fill_sweep_jitter(v4f *p, size_t nvec, uint32_t period, uint32_t burn)
+{
+    const v4f z = {0, 0, 0, 0};
+    uint32_t it = 0;
+    uint32_t blk = blockIdx.x;
+    if (MODE == 2) blk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    for (size_t v = (size_t)blk * 256 + threadIdx.x; v < nvec; v += (size_t)gridDim.x * 256, ++it) {
+        p[v] = z;
+        if (MODE != 2 && it % period == period - 1) {
+            uint32_t n = burn;
+            if (MODE == 1) n = (burn * (((blockIdx.x * 2654435761u + it * 40503u) >> 16) & 255u)) >> 7;   // 0 .. 2 x burn
+            const long long t0 = clock64();
+            while (clock64() - t0 < (long long)n) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+
+template <typename F>
+static float timed(F launch_, hipStream_t st)
+{
+    auto launch = [&] { launch_(); ++g_iter; };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
@@ -65,17 +113,22 @@ static float timed(F launch, hipStream_t st)
     return ms * 10.0f;   // us per launch
 }
 
-int main()
+// usage: fill_shapes [sets [images]]   sets > 1: consecutive launches write different buffers (sets x 221 MB in
+// rotation), so nothing is absorbed by the 256 MB Infinity Cache
+int main(int argc, char **argv)
 {
-    const size_t bytes = 64ull * 10647 * 81 * 4;            // config 2's label tensor: 220.8 MB
+    const int sets = argc > 1 ? atoi(argv[1]) : 1;
+    const size_t images = argc > 2 ? (size_t)atoi(argv[2]) : 64;
+    const size_t bytes = images * 10647 * 81 * 4;           // config 2's label tensor: 220.8 MB at 64 images
     const size_t nvec = bytes / 16;
-    v4f *p;
-    CHECK(hipMalloc(&p, bytes + 4096));
+    v4f *bufs[16];
+    for (int i = 0; i < sets && i < 16; ++i) CHECK(hipMalloc(&bufs[i], bytes + 4096));
+#define p (bufs[g_iter % sets])
     hipStream_t st;
     CHECK(hipStreamCreate(&st));
     const uint32_t per_block = 256 * 81 / 4;                // one 256-anchor tile: 5184 vectors = 83 KB
     const uint32_t blocks = (uint32_t)((nvec + per_block - 1) / per_block);
-    printf("bytes %zu, tile blocks %u\n", bytes, blocks);
+    printf("bytes %zu, tile blocks %u, %d buffer(s) in rotation\n", bytes, blocks, sets);
     printf("hipMemsetAsync            %.2f us\n", timed([&] { CHECK(hipMemsetAsync(p, 0, bytes, st)); }, st));
     printf("A block chunk (tile)      %.2f us\n", timed([&] { fill_block_chunk<<<blocks, 256, 0, st>>>(p, per_block, nvec); }, st));
     for (uint32_t pb : {1024u, 2048u, 10368u, 20736u}) {
@@ -84,6 +137,19 @@ int main()
     }
     for (uint32_t g : {256u, 512u, 1024u, 2048u, 4096u, 8192u})
         printf("B grid stride %5u blocks %.2f us\n", g, timed([&] { fill_grid_stride<<<g, 256, 0, st>>>(p, nvec); }, st));
+    for (uint32_t lds : {20u, 36u, 50u, 70u, 100u})
+        printf("E tile chunk, %3u KB LDS/block %.2f us\n", lds, timed([&] { fill_block_chunk_occ<<<blocks, 256, lds * 1024, st>>>(p, per_block, nvec); }, st));
+    for (uint32_t g : {256u, 512u, 768u, 1024u, 2048u}) {
+        printf("F persistent tiles %4u blocks %.2f us", g, timed([&] { fill_tiles_persistent<false><<<g, 256, 0, st>>>(p, per_block, blocks, nvec); }, st));
+        printf("   nt %.2f us\n", timed([&] { fill_tiles_persistent<true><<<g, 256, 0, st>>>(p, per_block, blocks, nvec); }, st));
+    }
+    for (uint32_t g : {256u, 512u}) {
+        printf("G sweep %u blocks: XCD-contiguous rows %.2f us", g, timed([&] { fill_sweep_jitter<2><<<g, 256, 0, st>>>(p, nvec, 20, 0); }, st));
+        for (uint32_t burn : {1000u, 3000u, 6000u})      // clock64 ticks at 100 MHz: 10 / 30 / 60 us?  (s_memtime domain) -- printed relative
+            printf("   burn %u fixed %.2f us, random %.2f us", burn, timed([&] { fill_sweep_jitter<0><<<g, 256, 0, st>>>(p, nvec, 20, burn); }, st),
+                   timed([&] { fill_sweep_jitter<1><<<g, 256, 0, st>>>(p, nvec, 20, burn); }, st));
+        printf("\n");
+    }
     printf("C 64 B per thread (tile)  %.2f us\n", timed([&] { fill_thread64<<<blocks, 256, 0, st>>>(p, per_block, nvec); }, st));
     printf("D sc1                     %.2f us\n", timed([&] { fill_block_chunk_asm<0><<<blocks, 256, 0, st>>>(p, per_block, nvec); }, st));
     printf("D nt                      %.2f us\n", timed([&] { fill_block_chunk_asm<1><<<blocks, 256, 0, st>>>(p, per_block, nvec); }, st));
