@@ -241,7 +241,7 @@ def match_encode_case(lib, dev, stream, cfg, B, anchors, seed, sets):
         reg, labels = outs[i % sets]
         rc = lib.odbox_match_encode(anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C,
                                     float(S), float(S), 0.4, 0.5, reg.data_ptr(), labels.data_ptr(),
-                                    None, None, None, stream)
+                                    None, None, None, None, stream)
         if rc:
             _lib.check(rc, 'odbox_match_encode')
     return step, dict(S=S, B=B, N=N, G=G, C=C, gt_np=gt_np, lab_np=lab_np, gt=gt, lab=lab, outs=outs,

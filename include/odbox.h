@@ -52,13 +52,19 @@ int odbox_anchor_tile(const float *base /*[A,4]*/, int A, int fh, int fw, float 
  * out_match_idx (argmax GT per anchor), out_state (-1 ignore / 0 background / 1 foreground)
  * and out_max_iou are compact side outputs.  Any out_* may be NULL (skipped); gt_labels may
  * be NULL when out_labels is NULL.  img_h / img_w = +inf disables the out-of-image test
- * (that is compute_gt_annotations on its own). */
+ * (that is compute_gt_annotations on its own).
+ * out_gt_best [B,G] (8-byte aligned, or NULL): for every ground-truth row the anchor with the
+ * largest IoU over all N anchors and that IoU -- argmax / max of bndbox.py:254-299's matrix over its
+ * ANCHOR axis, ties to the lowest anchor, padded rows (anchor 0, -1).  An extra output: the
+ * reference never forces a match from it (anchors.py:253-272 is per-anchor only; its one per-GT
+ * argmax is the diagnostic at coco.py:399-402), so no other output changes by a bit. */
+typedef struct odbox_gt_best { int32_t anchor; float iou; } odbox_gt_best_t;
 int odbox_match_encode(const float *anchors /*[N,4]*/, const float *gt_boxes /*[B,G,4]*/,
                        const int32_t *gt_labels /*[B,G]*/, int B, int N, int G, int C,
                        float img_h, float img_w, float neg_thr, float pos_thr,
                        float *out_regression /*[B,N,5]*/, float *out_labels /*[B,N,C+1]*/,
                        int32_t *out_match_idx /*[B,N]*/, int8_t *out_state /*[B,N]*/,
-                       float *out_max_iou /*[B,N]*/, void *stream);
+                       float *out_max_iou /*[B,N]*/, odbox_gt_best_t *out_gt_best /*[B,G]*/, void *stream);
 
 /* Fused matcher + loss, the consumer of the targets: metric.py:97-123 (ModelMetric.__call__) with
  * focal_loss (metric.py:9-38: clip to [1e-6, 1-1e-6], alpha_t, pow(1-pt, gamma), log) and

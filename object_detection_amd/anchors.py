@@ -87,10 +87,12 @@ def _image_hw(images):
 
 def match_encode(anchors, image_hw, bndboxes, labels, num_classes,
                  negative_overlap=0.4, positive_overlap=0.5,
-                 dense=True, compact=False):
+                 dense=True, compact=False, gt_best=False):
     """Fused matcher + encoder (`odbox_match_encode`).  Returns a dict with `regression`
-    [B,N,5] / `labels` [B,N,C+1] when dense, and `match_idx` i32 / `state` i8 / `max_iou` f32
-    [B,N] when compact."""
+    [B,N,5] / `labels` [B,N,C+1] when dense, `match_idx` i32 / `state` i8 / `max_iou` f32
+    [B,N] when compact, and `gt_best_anchor` i32 / `gt_best_iou` f32 [B,G] (views of one record
+    tensor) when gt_best: per ground-truth row the anchor with the largest IoU, ties to the lowest
+    anchor -- an extra output that never changes the others."""
     lib = _lib.load()
     dev = _lib.require_gpu()
     anchors = _lib.as_dev(anchors, torch.float32, dev)
@@ -115,12 +117,26 @@ def match_encode(anchors, image_hw, bndboxes, labels, num_classes,
         midx = out['match_idx'] = torch.empty((B, N), dtype=torch.int32, device=dev)
         state = out['state'] = torch.empty((B, N), dtype=torch.int8, device=dev)
         miou = out['max_iou'] = torch.empty((B, N), dtype=torch.float32, device=dev)
+    best = None
+    if gt_best:
+        best = torch.empty((B, G, 2), dtype=torch.int32, device=dev)          # odbox_gt_best_t records
+        out['gt_best_anchor'] = best[..., 0]
+        out['gt_best_iou'] = best.view(torch.float32)[..., 1]
     _lib.check(lib.odbox_match_encode(
         _lib.ptr(anchors), _lib.ptr(bndboxes), _lib.ptr(labels), B, N, G, C,
         float(image_hw[0]), float(image_hw[1]), float(negative_overlap), float(positive_overlap),
-        _lib.ptr(reg), _lib.ptr(lab), _lib.ptr(midx), _lib.ptr(state), _lib.ptr(miou),
+        _lib.ptr(reg), _lib.ptr(lab), _lib.ptr(midx), _lib.ptr(state), _lib.ptr(miou), _lib.ptr(best),
         _lib.stream_ptr()), 'odbox_match_encode')
     return out
+
+
+def gt_best_anchors(anchors, annotations):
+    """Per ground-truth row, the anchor with the largest IoU and that IoU: `(best_anchor [B,G] int32,
+    best_iou [B,G] float32)` = argmax / max of `bbox_overlap(anchors, annotations)` over its anchor
+    axis (ties to the lowest anchor; padded rows give (0, -1)).  The reference has no forced
+    per-GT match (anchors.py:253-272); its only per-GT argmax is the diagnostic of coco.py:399-402."""
+    r = match_encode(anchors, (_INF, _INF), annotations, None, 1, dense=False, compact=False, gt_best=True)
+    return r['gt_best_anchor'], r['gt_best_iou']
 
 
 def anchor_targets_bbox(anchors, images, bndboxes, labels, num_classes: int,

@@ -129,13 +129,31 @@ struct TileMatch {
 // REDUCE_LATE: the wave's bounding-box reduction runs after `early` (so it, too, overlaps what was
 // issued there: 34.5 vs 34.9 us for match+encode on config 2) instead of before the GT staging
 // (better for the loss kernel, whose prefetched score load is in flight meanwhile: 45.0 vs 45.9 us).
-template <int TILE, bool REDUCE_LATE, typename EarlyWork>
+//
+// GTBEST (match_encode_kernel only): the per-GT best anchor, an EXTRA output that changes nothing of
+// the above (north_star's "per-GT best-anchor" reduction; the reference only has the diagnostic of
+// coco.py:399-402 and never forces a label from it).  For GT row g of image b: the anchor with the
+// largest IoU over all N anchors, ties to the LOWEST anchor (numpy / tf argmax over the anchor axis).
+// Every lane that evaluates a pair with IoU > 0 folds (ordered IoU bits, ~anchor) into the row's
+// 64-bit LDS maximum; per chunk each row's maximum goes to gbest_keys[b, g] with one global
+// atomicMax, and only if a plain load says it can still win.  Pairs the culling proves to be exactly
+// +0 post nothing: a row nobody posted for has IoU +0 everywhere (or -1: padding) and its argmax
+// is anchor 0 -- filled in by gt_best_finalize_kernel, which also recomputes the winner's IoU, so the
+// value carries the exact bits of IoU(anchor, g), sign of zero included.  Rows that cannot be
+// culled (negative-area GT rows or anchors: values below zero are possible) post every pair.
+__device__ __forceinline__ unsigned long long gbest_key(float v, uint32_t n)
+{
+    return ((unsigned long long)f32_ordered(v) << 32) | (0xffffffffu - n);
+}
+
+template <int TILE, bool REDUCE_LATE, bool GTBEST = false, typename EarlyWork>
 __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ anchors,
                                                 const float4 *__restrict__ gt_boxes,
                                                 const int32_t *__restrict__ gt_labels, uint32_t b, uint32_t n0, int N,
                                                 int G, int C, float img_h, float img_w, float neg_thr, float pos_thr,
-                                                EarlyWork early)
+                                                EarlyWork early, unsigned long long *gbest_keys = nullptr)
 {
+    __shared__ unsigned long long s_gbest[GTBEST ? ME_GCHUNK : 1];
     __shared__ float4 s_gt[ME_GCHUNK];
     __shared__ float2 s_ga[ME_GCHUNK];          // (area, 1.0 if padded row else 0.0)
     __shared__ uint16_t s_list[TILE / WAVE][ME_GCHUNK];      // per wave: GT rows it must evaluate
@@ -180,6 +198,7 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
             float gmax = fmaxf(fmaxf(gb.x, gb.y), fmaxf(gb.z, gb.w));    // bndbox.py:295
             s_gt[g] = gb;
             s_ga[g] = make_float2(area, gmax < 0.0f ? 1.0f : 0.0f);
+            if (GTBEST) s_gbest[g] = 0ull;
         }
         // every global load issued so far has been consumed: from here to the label / box gathers at
         // the end the match is VALU and LDS work only, so memory work issued now overlaps it
@@ -218,6 +237,21 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
             const float2 ga = s_ga[g];
             const float v = pair_iou(a, a_area, gb, ga.x);               // never a padded row here
             if (v > best_iou) { best_iou = v; best = g0 + g; }           // tf.argmax: first max
+            if (GTBEST) {
+                const bool forced = !can_skip_zero || !(ga.x >= 0.0f);
+                if (live && (v > 0.0f || forced)) atomicMax(&s_gbest[g], gbest_key(v, n));
+            }
+        }
+        if (GTBEST) {
+            __syncthreads();                                 // every wave's maxima of this chunk are in
+            unsigned long long *dst = gbest_keys + (size_t)b * G + g0;
+            for (int g = tid; g < cnt; g += TILE) {
+                const unsigned long long k = s_gbest[g];
+                // look before posting (a device-scope load: a plain one would be served by this XCD's L2, which
+                // never sees the other XCDs' atomics).  A stale value errs on the low side only (the keys only
+                // grow): a useless atomic at worst, never a skipped one
+                if (k != 0ull && k > __hip_atomic_load(&dst[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&dst[g], k);
+            }
         }
     }
     // fold the skipped rows back in: value 0 at first_zero, value -1 at first_pad; ties go to
@@ -255,13 +289,13 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
 // that fit the 256 MB Infinity Cache (cfg 2: 234 MB) are 1.5x FASTER with plain stores, outputs far
 // beyond it (cfg 3: 2.2 GB per GPU) 6 % faster bypassing it.  The streaming variant also runs
 // 128-anchor tiles (cfg 3), the small launches prefer 256 (cfg 2: 128 and 512 are both slower).
-template <bool STREAM>
+template <bool STREAM, bool GTBEST>
 __global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE_ENC) void match_encode_kernel(
     const float4 *__restrict__ anchors, const float4 *__restrict__ gt_boxes,
     const int32_t *__restrict__ gt_labels, int N, int G, int C, float img_h, float img_w,
     float neg_thr, float pos_thr, float *__restrict__ out_reg, float *__restrict__ out_lab,
     int32_t *__restrict__ out_idx, int8_t *__restrict__ out_state, float *__restrict__ out_iou,
-    uint32_t tiles_per_image, uint32_t remap)
+    unsigned long long *gbest_keys, uint32_t tiles_per_image, uint32_t remap)
 {
     constexpr int TILE = STREAM ? ME_TILE_STREAM : ME_TILE_ENC;
     __shared__ float s_reg[TILE * 5];
@@ -315,8 +349,8 @@ __global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE_ENC) void match_e
     };
     if (ZERO_LEAD > 0) zero_stream(true);
 
-    const TileMatch tm = match_tile<TILE, true>(anchors, gt_boxes, gt_labels, b, n0, N, G, C, img_h, img_w, neg_thr, pos_thr,
-                                                [&] { zero_stream(false); });
+    const TileMatch tm = match_tile<TILE, true, GTBEST>(anchors, gt_boxes, gt_labels, b, n0, N, G, C, img_h, img_w, neg_thr,
+                                                        pos_thr, [&] { zero_stream(false); }, gbest_keys);
     const float4 a = tm.a;
     const float best_iou = tm.best_iou;
     const int best = tm.best, state = tm.state, label = tm.label;
@@ -876,6 +910,34 @@ __global__ __launch_bounds__(RED_THREADS) void loss_reduce_kernel(const float4 *
     }
 }
 
+// Per-GT best anchor (see match_tile): the keys start at 0 = "nobody posted" ...
+__global__ __launch_bounds__(256) void gt_best_init_kernel(unsigned long long *__restrict__ keys, uint32_t total)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < total) keys[i] = 0ull;
+}
+// ... and are turned, in place, into the records of include/odbox.h: { int32 anchor; float iou }.
+__global__ __launch_bounds__(256) void gt_best_finalize_kernel(const float4 *__restrict__ anchors,
+                                                               const float4 *__restrict__ gt, int N, int G,
+                                                               unsigned long long *keys, uint32_t total)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= total) return;
+    const unsigned long long k = keys[i];
+    uint32_t n = k != 0ull ? 0xffffffffu - (uint32_t)k : 0u;        // nobody posted: every IoU is +0 (or -1), argmax = 0
+    n = min(n, (uint32_t)N - 1u);
+    const float4 a = anchors[n];
+    const float4 gb = gt[i];                                         // i = b * G + g
+    const float a_area = (a.w - a.y) * (a.z - a.x);
+    const float g_area = (gb.w - gb.y) * (gb.z - gb.x);
+    const float gmax = fmaxf(fmaxf(gb.x, gb.y), fmaxf(gb.z, gb.w));
+    const float v = gmax < 0.0f ? -1.0f : pair_iou(a, a_area, gb, g_area);       // bndbox.py:289-297
+    int2 rec;
+    rec.x = (int)n;
+    rec.y = __float_as_int(v);
+    reinterpret_cast<int2 *>(keys)[i] = rec;
+}
+
 // ------------------------------------------------------------------------------------------
 // bndbox.py:254-299  dense [B,N,G] IoU (API parity; the training path never materialises it)
 // ------------------------------------------------------------------------------------------
@@ -965,7 +1027,7 @@ int odbox_anchor_tile(const float *base, int A, int fh, int fw, float stride, fl
 int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B, int N,
                        int G, int C, float img_h, float img_w, float neg_thr, float pos_thr,
                        float *out_regression, float *out_labels, int32_t *out_match_idx, int8_t *out_state,
-                       float *out_max_iou, void *stream)
+                       float *out_max_iou, odbox_gt_best_t *out_gt_best, void *stream)
 {
     if (B < 0 || N < 0 || G < 1 || C < 1 || C > ODBOX_MAX_CLASSES)
         return fail(ODBOX_EINVAL, "odbox_match_encode: bad shape B=%d N=%d G=%d C=%d (need G>=1, 1<=C<=%d)", B, N, G, C,
@@ -975,7 +1037,8 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
     if (out_labels && !gt_labels) return fail(ODBOX_EINVAL, "odbox_match_encode: out_labels needs gt_labels");
     if (!aligned16(anchors) || !aligned16(gt_boxes))
         return fail(ODBOX_EINVAL, "odbox_match_encode: anchors / gt_boxes must be 16-byte aligned");
-    if (B == 0 || N == 0) return 0;
+    if ((uintptr_t)out_gt_best & 7u) return fail(ODBOX_EINVAL, "odbox_match_encode: out_gt_best must be 8-byte aligned");
+    if (out_gt_best && (uint64_t)B * (uint64_t)G > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_match_encode: B * G too large");
     const uint32_t d = (uint32_t)C + 1u;
     // dense labels beyond twice the 256 MB Infinity Cache: bypass it, smaller tiles (see match_encode_kernel).
     // Tile order: whole images per XCD (xcd_remap) is balanced by construction and keeps an image's tiles
@@ -995,15 +1058,28 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
     const uint64_t tiles = ((uint64_t)N + tile - 1) / tile;
     const uint64_t blocks = tiles * (uint64_t)B;
     if (blocks > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_match_encode: grid too large");
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(out_gt_best);
+    const uint32_t bg = (uint32_t)B * (uint32_t)G;
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(tile), 0, (hipStream_t)stream,
                            (const float4 *)anchors, (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w,
                            neg_thr, pos_thr, out_regression, out_labels, out_match_idx, out_state, out_max_iou,
-                           (uint32_t)tiles, remap);
+                           keys, (uint32_t)tiles, remap);
     };
-    if (stream_out) launch(match_encode_kernel<true>);
-    else launch(match_encode_kernel<false>);
-    return launch_status("match_encode");
+    if (!keys) {
+        if (stream_out) launch(match_encode_kernel<true, false>);
+        else launch(match_encode_kernel<false, false>);
+        return launch_status("match_encode");
+    }
+    // per-GT best anchor: the records double as the 64-bit keys while the matcher runs
+    hipLaunchKernelGGL(gt_best_init_kernel, dim3((bg + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, keys, bg);
+    if (int rc = launch_status("gt_best_init")) return rc;
+    if (stream_out) launch(match_encode_kernel<true, true>);
+    else launch(match_encode_kernel<false, true>);
+    if (int rc = launch_status("match_encode")) return rc;
+    hipLaunchKernelGGL(gt_best_finalize_kernel, dim3((bg + 255u) / 256u), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)anchors, (const float4 *)gt_boxes, N, G, keys, bg);
+    return launch_status("gt_best_finalize");
 }
 
 size_t odbox_match_loss_workspace(int B, int N)

@@ -83,6 +83,17 @@ def match_encode(anchors, image_hw, gt_boxes, gt_labels, num_classes,
     return {'regression': reg, 'labels': lab, 'match_idx': midx, 'state': state, 'max_iou': miou}
 
 
+def gt_best(anchors, gt_boxes, threads=1):
+    """(best_anchor [B,G] i32, best_iou [B,G] f32): column argmax / max of the IoU matrix."""
+    anchors = _c(anchors, np.float32)
+    gt_boxes = _c(gt_boxes, np.float32)
+    B, G = gt_boxes.shape[0], gt_boxes.shape[1]
+    ba = np.empty((B, G), dtype=np.int32)
+    bi = np.empty((B, G), dtype=np.float32)
+    lib().odbox_oracle_gt_best(_p(anchors, _f), _p(gt_boxes, _f), B, anchors.shape[0], G, _p(ba, _i), _p(bi, _f), int(threads))
+    return ba, bi
+
+
 def regress_boxes(boxes, regress):
     boxes = _c(boxes, np.float32)
     regress = _c(regress, np.float32)

@@ -131,6 +131,34 @@ void odbox_oracle_match_encode(const float *anchors, const float *gt_boxes, cons
     }
 }
 
+/*
+ * Per ground-truth row: argmax / max of the IoU matrix of bndbox.py:254-299 over its ANCHOR axis
+ * (np.argmax / tf.argmax semantics: the first maximal index; -0 == +0).  The reference holds no such
+ * output on its live path -- anchors.py:253-272 is per-anchor only; the one per-GT argmax is the
+ * diagnostic `max_iou_idx = np.argmax(ious)` of coco.py:399-402 -- so this restates the definition
+ * the extra output of odbox_match_encode (out_gt_best) is held to.
+ */
+void odbox_oracle_gt_best(const float *anchors, const float *gt_boxes, int B, int N, int G,
+                          int32_t *out_anchor, float *out_iou, int threads)
+{
+#ifdef _OPENMP
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+#endif
+    for (int b = 0; b < B; ++b)
+        for (int g = 0; g < G; ++g) {
+            const float *gb = gt_boxes + ((size_t)b * G + g) * 4;
+            int best = 0;
+            float best_iou = 0.0f;
+            for (int n = 0; n < N; ++n) {
+                float v = overlap_pair(anchors + (size_t)n * 4, gb);
+                if (n == 0 || v > best_iou) { best = n; best_iou = v; }
+            }
+            out_anchor[(size_t)b * G + g] = best;
+            out_iou[(size_t)b * G + g] = best_iou;
+        }
+}
+
 /* bndbox.py:88-99 */
 static inline void decode_box(const float *a, const float *r, float *o)
 {

@@ -131,6 +131,19 @@ def compute_gt_annotations(anchors, annotations, negative_overlap=0.4, positive_
     return positive, ignore, batched, maxv
 
 
+def gt_best_anchors(anchors, annotations):
+    """Per ground-truth row, (argmax, max) of `bbox_overlap` over its anchor axis (first maximal
+    anchor).  Not on the reference's live path (anchors.py:253-272 is per-anchor only); its only
+    per-GT argmax is the diagnostic `np.argmax(ious)` of coco.py:399-402.  Definition of the extra
+    output `out_gt_best` of odbox_match_encode."""
+    annotations = np.asarray(annotations, dtype=np.float32)
+    B = annotations.shape[0]
+    a = np.broadcast_to(np.asarray(anchors, dtype=np.float32), (B,) + np.shape(anchors))
+    iou = bbox_overlap(a, annotations)                     # [B,N,G]
+    idx = np.argmax(iou, axis=1).astype(np.int32)          # [B,G]
+    return idx, np.take_along_axis(iou, idx[:, None, :], axis=1)[:, 0, :]
+
+
 def bbox_transform(anchors, gt_boxes):
     """anchors.py:277-299: offsets / anchor size, then (t - 0) / 0.2f (a true fp32 division)."""
     a = _f32(anchors)

@@ -18,6 +18,8 @@
 
 extern "C" {
 void odbox_oracle_anchor_tile(const float *base, int A, int fh, int fw, float stride, float *out);
+void odbox_oracle_gt_best(const float *anchors, const float *gt_boxes, int B, int N, int G, int32_t *out_anchor,
+                          float *out_iou, int threads);
 void odbox_oracle_match_encode(const float *anchors, const float *gt_boxes, const int32_t *gt_labels, int B, int N, int G,
                                int C, float img_h, float img_w, float neg_thr, float pos_thr, float *out_regression,
                                float *out_labels, int32_t *out_match_idx, int8_t *out_state, float *out_max_iou,
@@ -119,9 +121,22 @@ int main()
     HIP_OK(hipMalloc((void **)&d_lbl, lbl.size() * sizeof(float)));
     HIP_OK(hipMalloc((void **)&d_midx, midx.size() * sizeof(int32_t)));
     HIP_OK(hipMalloc((void **)&d_state, state.size()));
+    odbox_gt_best_t *d_best = nullptr;
+    std::vector<odbox_gt_best_t> best((size_t)B * G);
+    HIP_OK(hipMalloc((void **)&d_best, best.size() * sizeof(odbox_gt_best_t)));
     ODBOX_OK(odbox_match_encode(d_anchors, d_gt, d_lab, B, N, G, C, (float)S, (float)S, 0.4f, 0.5f, d_reg, d_lbl, d_midx,
-                                d_state, nullptr, st));
+                                d_state, nullptr, d_best, st));
     HIP_OK(hipStreamSynchronize(st));
+    HIP_OK(hipMemcpy(best.data(), d_best, best.size() * sizeof(odbox_gt_best_t), hipMemcpyDeviceToHost));
+    {
+        std::vector<int32_t> ba(best.size());
+        std::vector<float> bi(best.size());
+        odbox_oracle_gt_best(anchors_ref.data(), gt.data(), B, N, G, ba.data(), bi.data(), 1);
+        size_t bad_best = 0;
+        for (size_t i = 0; i < best.size(); ++i) bad_best += best[i].anchor != ba[i] || best[i].iou != bi[i];
+        printf("gt_best: %zu (anchor, IoU) mismatches over %zu ground-truth rows\n", bad_best, best.size());
+        failures += bad_best;
+    }
     if (!from_device(reg, d_reg) || !from_device(lbl, d_lbl) || !from_device(midx, d_midx) || !from_device(state, d_state)) return 2;
     bad = 0;
     size_t fg = 0;

@@ -46,7 +46,7 @@ def test_workspace_query_needs_no_gpu(lib):
 
 
 def test_argument_validation_happens_before_any_gpu_work(lib):
-    rc = lib.odbox_match_encode(None, None, None, 1, 1, 1, 1, 1.0, 1.0, 0.4, 0.5, None, None, None, None, None, None)
+    rc = lib.odbox_match_encode(None, None, None, 1, 1, 1, 1, 1.0, 1.0, 0.4, 0.5, None, None, None, None, None, None, None)
     assert rc == -1 and b'NULL' in lib.odbox_last_error()
 
 
@@ -154,9 +154,10 @@ def test_every_entry_rejects_bad_arguments_without_touching_the_gpu(lib):
     cases = [
         ('odbox_anchor_tile', (None, 9, 4, 4, 8.0, p, None), -1),
         ('odbox_anchor_tile', (p, -1, 4, 4, 8.0, p, None), -1),
-        ('odbox_match_encode', (p, p, p, 1, 4, 2, 0, 8.0, 8.0, 0.4, 0.5, p, p, None, None, None, None), -1),      # C < 1
-        ('odbox_match_encode', (odd, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, None, None, None, None), -1),    # alignment
-        ('odbox_match_encode', (p, p, None, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, None, None, None, None), -1),   # labels needed
+        ('odbox_match_encode', (p, p, p, 1, 4, 2, 0, 8.0, 8.0, 0.4, 0.5, p, p, None, None, None, None, None), -1),      # C < 1
+        ('odbox_match_encode', (odd, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, None, None, None, None, None), -1),    # alignment
+        ('odbox_match_encode', (p, p, None, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, None, None, None, None, None), -1),   # labels needed
+        ('odbox_match_encode', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, None, None, None, odd, None), -1),   # out_gt_best 8-byte aligned
         ('odbox_match_loss', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, p, p, None, p, 1 << 20, None), -1),   # one gradient only
         ('odbox_match_loss', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, p, None, None, p, 4, None), -3),        # workspace
         ('odbox_match_loss_noalloc', (p, p, p, 1, 4, 2, 2, 8.0, 8.0, 0.4, 0.5, p, p, 1.5, 0.25, 1.0, None, None, None, None), -1),      # no out_loss

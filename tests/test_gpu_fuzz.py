@@ -62,7 +62,7 @@ def test_match_encode_random_shapes_and_placements(seed):
     a, g, l = (torch.as_tensor(x).to(dev) for x in (anchors, gt, lab))
     p = lambda t, on=True: ctypes.c_void_p(t.data_ptr()) if on else None      # noqa: E731
     rc = lib.odbox_match_encode(p(a), p(g), p(l), B, N, G, C, hw[0], hw[1], 0.4, 0.5, p(reg, want_reg), p(labels, want_lab),
-                                p(idx, want_compact), p(state, want_compact), p(iou, want_compact), _lib.stream_ptr())
+                                p(idx, want_compact), p(state, want_compact), p(iou, want_compact), None, _lib.stream_ptr())
     assert rc == 0, lib.odbox_last_error()
     torch.cuda.synchronize()
     if want_lab:

@@ -40,7 +40,7 @@ def test_match_encode_and_decode_nms_replay_from_a_hip_graph():
     def enqueue():
         st = _lib.stream_ptr()
         rc = lib.odbox_match_encode(anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, Gp, C, float(S), float(S),
-                                    0.4, 0.5, out_reg.data_ptr(), out_lab.data_ptr(), None, None, None, st)
+                                    0.4, 0.5, out_reg.data_ptr(), out_lab.data_ptr(), None, None, None, None, st)
         assert rc == 0, lib.odbox_last_error()
         rc = lib.odbox_decode_nms(anchors.data_ptr(), reg.data_ptr(), sc.data_ptr(), B, N, C, float(S), float(S), 1,
                                   0.3, 0.45, 100, 0, det_b.data_ptr(), det_s.data_ptr(), det_l.data_ptr(),

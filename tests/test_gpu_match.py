@@ -241,7 +241,7 @@ def test_unaligned_dense_outputs_and_odd_shapes(C, N, off):
     reg = reg_buf[off:off + B * N * 5]
     out = lab_buf[off:off + B * N * (C + 1)]
     rc = lib.odbox_match_encode(a.data_ptr(), g_.data_ptr(), l_.data_ptr(), B, N, G + 2, C, float(S), float(S), 0.4, 0.5,
-                                reg.data_ptr(), out.data_ptr(), None, None, None, _lib.stream_ptr())
+                                reg.data_ptr(), out.data_ptr(), None, None, None, None, _lib.stream_ptr())
     assert rc == 0, lib.odbox_last_error()
     ref = c_oracle.match_encode(anchors, (S, S), gt, lab, C, threads=4)
     np.testing.assert_array_equal(cpu(out).reshape(B, N, C + 1), ref['labels'])

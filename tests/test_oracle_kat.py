@@ -268,3 +268,27 @@ def test_restore_detections_known_answers():
     s = 300 / 512
     np.testing.assert_array_equal(out[1, 0], [100 * s - 50, 100 * s, 200 * s - 50, 200 * s])
     np.testing.assert_array_equal(out[1, 1], [0, 0, 0, 0])
+
+
+def test_gt_best_anchor_known_answers_and_two_restatements_agree():
+    """Per-GT best anchor (the extra output of odbox_match_encode): hand-derived cases, NumPy vs C."""
+    from oracle import c_oracle
+    anchors = np.array([[0, 0, 10, 10], [0, 0, 10, 5], [0, 0, 10, 10], [20, 20, 30, 30]], np.float32)
+    gt = np.array([[[0, 0, 10, 10],        # IoU 1 with anchors 0 and 2: the lower one wins
+                    [0, 0, 10, 4],         # 40/50 with anchor 1 (0.8) beats 40/100
+                    [100, 100, 110, 110],  # touches nothing: all +0 -> anchor 0
+                    [-1, -1, -1, -1]]], np.float32)   # padding: all -1 -> anchor 0
+    idx, iou = O.gt_best_anchors(anchors, gt)
+    np.testing.assert_array_equal(idx, [[0, 1, 0, 0]])
+    np.testing.assert_allclose(iou, [[1.0, 0.8, 0.0, -1.0]], rtol=1e-6)
+    cidx, ciou = c_oracle.gt_best(anchors, gt)
+    np.testing.assert_array_equal(cidx, idx)
+    np.testing.assert_array_equal(ciou, iou)
+    from object_detection_amd import workloads
+    rng = np.random.default_rng(4)
+    a = O.generate_anchors(128)
+    g = np.stack([workloads.gt_boxes(rng, 128, 9, 3, pad_to=12)[0] for _ in range(3)])
+    i1, v1 = O.gt_best_anchors(a, g)
+    i2, v2 = c_oracle.gt_best(a, g, threads=2)
+    np.testing.assert_array_equal(i1, i2)
+    np.testing.assert_array_equal(v1, v2)

@@ -73,7 +73,7 @@ def main():
 
         def step():
             rc = lib.odbox_match_encode(anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C, float(c['S']),
-                                        float(c['S']), 0.4, 0.5, reg.data_ptr(), out.data_ptr(), None, None, None, st)
+                                        float(c['S']), 0.4, 0.5, reg.data_ptr(), out.data_ptr(), None, None, None, None, st)
             assert rc == 0
         t = event_time(step, args.iters)
         byts = B * workloads.match_bytes_per_image(N, G, C)
@@ -92,7 +92,7 @@ def main():
             def step_compact():
                 rc = lib.odbox_match_encode(anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C, float(c['S']),
                                             float(c['S']), 0.4, 0.5, reg.data_ptr(), None, idx.data_ptr(), state.data_ptr(),
-                                            None, st)
+                                            None, None, st)
                 assert rc == 0
             t = event_time(step_compact, args.iters)
             byts = B * (N * (16 + 20 + 5) + 20 * G)

@@ -29,7 +29,7 @@ for name, (gt, lab) in cases.items():
 
     def step():
         assert lib.odbox_match_encode(anchors.data_ptr(), g.data_ptr(), l.data_ptr(), B, N, G, C, float(S), float(S), 0.4, 0.5,
-                                      reg.data_ptr(), labels.data_ptr(), None, None, None, st) == 0
+                                      reg.data_ptr(), labels.data_ptr(), None, None, None, None, st) == 0
     for _ in range(10):
         step()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

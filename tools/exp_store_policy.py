@@ -25,7 +25,7 @@ for B in [int(b) for b in os.environ.get('SWEEP_B', '16 32 40 48 56 64 80 100').
 
     def step():
         assert lib.odbox_match_encode(anchors.data_ptr(), g.data_ptr(), l.data_ptr(), B, N, g.shape[1], C, float(S), float(S),
-                                      0.4, 0.5, reg.data_ptr(), labels.data_ptr(), None, None, None, st) == 0
+                                      0.4, 0.5, reg.data_ptr(), labels.data_ptr(), None, None, None, None, st) == 0
     for _ in range(10):
         step()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
