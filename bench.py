@@ -286,9 +286,16 @@ def main():
     assert anchors.shape[0] == workloads.num_anchors(2)
     step, w = match_encode_case(lib, dev, stream, 2, workloads.CONFIGS[2]['B'], anchors, 1002 + 7919 * rank, OUTPUT_SETS)
     S, B, N, G, C = w['S'], w['B'], w['N'], w['G'], w['C']
+    # outputs that nothing reads back soon are written around the caches: the caller says so
+    # (odbox_set_output_policy, anchors.set_output_policy('stream')); the library's size rule alone
+    # (`auto`) would send 221 MB of labels through them
+    lib.odbox_set_output_policy(2)
     wall, ev = timed(step, args.steps, args.warmup, world)
     med, _ = per_step_median(step)
     img_s = world * B * args.steps / wall
+    lib.odbox_set_output_policy(0)
+    _, ev0 = timed(step, args.steps, args.warmup, 1)                   # the same rotation under the default policy
+    med0, _ = per_step_median(step)
     # the same launch rewriting ONE output set every step: its 245 MB fit the Infinity Cache
     _, ev1 = timed(lambda i: step(0), args.steps, args.warmup, 1)
     med1, _ = per_step_median(lambda i: step(0))
@@ -308,14 +315,19 @@ def main():
         'data': 'synthetic',
         'config': {'workload': 'configs[1]: YOLOv3-shaped 416x416 grid, 3 strides x 3 anchors = %d anchors, '
                                '%d classes, %d GT boxes/img, batch %d per GPU, dense [B,N,5]+[B,N,C+1] outputs, '
-                               '%d output sets in rotation (%.2f GB) so that no step is absorbed by the Infinity Cache'
+                               '%d output sets in rotation (%.2f GB) so that no step is absorbed by the Infinity Cache, '
+                               "output policy 'stream' (targets nothing reads back soon)"
                                % (N, C, G, B, OUTPUT_SETS, OUTPUT_SETS * B * N * (C + 6) * 4 / 1e9),
                    'global_batch': world * B, 'anchors': N, 'classes': C, 'gt_per_image': G,
                    'parallelism': 'images sharded over %d GPU(s), no collective' % world},
         'roofline': hbm_roofline('match_encode_kernel', w['bytes'], ev / args.steps, med, 'match_encode_kernel_rotating',
-                                 output_sets=OUTPUT_SETS),
+                                 output_sets=OUTPUT_SETS, output_policy='stream'),
+        'roofline_auto_policy': hbm_roofline(
+            'match_encode_kernel', w['bytes'], ev0 / args.steps, med0, None, output_sets=OUTPUT_SETS, output_policy='auto',
+            note='the same rotation under the default policy (through the caches up to 512 MB of labels): what a caller '
+                 'that says nothing about its consumer gets on cold buffers'),
         'roofline_cache_resident': hbm_roofline(
-            'match_encode_kernel', w['bytes'], ev1 / args.steps, med1, 'match_encode_kernel',
+            'match_encode_kernel', w['bytes'], ev1 / args.steps, med1, 'match_encode_kernel', output_policy='auto',
             note='one output set rewritten every step: the 245 MB of stores fit the 256 MB Infinity Cache, so this is '
                  'a cache-assisted store rate, not an HBM fraction'),
     }
@@ -337,8 +349,10 @@ def main():
             if anch is None:
                 anch = A.generate_anchors(A.AnchorsConfig(), workloads.CONFIGS[cfg]['S'])
             stepc, wc = match_encode_case(lib, dev, stream, cfg, Bc, anch, 1000 + cfg + 7919 * rank, sets)
+            lib.odbox_set_output_policy(2 if sets > 2 else 0)           # rotating (cold) outputs: written around the caches
             wl, el = timed(stepc, ksteps, 3, world)
             medc, _ = per_step_median(stepc, per_group=5)
+            lib.odbox_set_output_policy(0)
             sub = {'value': round(world * Bc * ksteps / wl, 1), 'unit': 'images/s', 'steps': ksteps,
                    'config': {'workload': label}}
             if cfg == 4:
@@ -353,7 +367,8 @@ def main():
                                    'frac_source': 'static: VALU-busy cycles / launch cycles from the SQ counter passes '
                                                   '(tools/pmc_cfg.sh 4, profiles/), not measured in this run'}
             else:
-                sub['roofline'] = hbm_roofline('match_encode_kernel', wc['bytes'], el / ksteps, medc, None, output_sets=sets)
+                sub['roofline'] = hbm_roofline('match_encode_kernel', wc['bytes'], el / ksteps, medc, None, output_sets=sets,
+                                               output_policy='stream' if sets > 2 else 'auto')
             result[key] = sub
             del stepc, wc
         torch.cuda.empty_cache()

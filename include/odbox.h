@@ -41,6 +41,18 @@ extern "C" {
 int odbox_version(void);
 const char *odbox_last_error(void);
 
+/* How odbox_match_encode writes its dense outputs (no counterpart in the reference: a property of this
+ * GPU's memory system).  AUTO (default): through the caches while the label tensor is at most 512 MB
+ * -- right when the consumer reads the targets next, or when one buffer is rewritten every step (it is
+ * still in the 256 MB Infinity Cache) -- and around them (nontemporal stores) beyond.  CACHE / STREAM
+ * force one or the other; STREAM is for outputs nothing reads soon (targets computed ahead by the
+ * input pipeline into a fresh buffer every call).  Process-wide; returns the previous policy, or
+ * ODBOX_EINVAL.  Results are bit-identical under every policy. */
+#define ODBOX_POLICY_AUTO   0
+#define ODBOX_POLICY_CACHE  1
+#define ODBOX_POLICY_STREAM 2
+int odbox_set_output_policy(int policy);
+
 /* anchors.py:44-87 AnchorGenerator.tile_anchors_over_feature_map:
  * out[(i*fw + j)*A + a] = base[a] + ((j+.5)*stride, (i+.5)*stride, (j+.5)*stride, (i+.5)*stride). */
 int odbox_anchor_tile(const float *base /*[A,4]*/, int A, int fh, int fw, float stride,

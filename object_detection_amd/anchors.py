@@ -85,6 +85,20 @@ def _image_hw(images):
     raise ValueError('images must be [B,H,W,C] (or its shape, or (H, W)); got %r' % (shape,))
 
 
+_POLICIES = {'auto': 0, 'cache': 1, 'stream': 2}
+
+
+def set_output_policy(policy: str) -> str:
+    """How `anchor_targets_bbox` / `match_encode` write their dense outputs (`odbox_set_output_policy`):
+    'auto' (through the caches up to 512 MB of labels, around them beyond), 'cache', or 'stream' (for
+    targets nothing reads soon, e.g. computed ahead of the training step into a fresh buffer every
+    call).  Same bits either way.  Returns the previous policy."""
+    if policy not in _POLICIES:
+        raise ValueError("policy must be 'auto', 'cache' or 'stream'")
+    prev = _lib.load().odbox_set_output_policy(_POLICIES[policy])
+    return {v: k for k, v in _POLICIES.items()}[prev]
+
+
 def match_encode(anchors, image_hw, bndboxes, labels, num_classes,
                  negative_overlap=0.4, positive_overlap=0.5,
                  dense=True, compact=False, gt_best=False):

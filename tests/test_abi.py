@@ -197,6 +197,9 @@ def test_every_entry_rejects_bad_arguments_without_touching_the_gpu(lib):
         rc = getattr(lib, name)(*args)
         assert rc == want, (name, rc, lib.odbox_last_error())
         assert name.encode() in lib.odbox_last_error(), (name, lib.odbox_last_error())
+    # the output policy is a process-wide setting: unknown values are refused, a valid call returns the previous one
+    assert lib.odbox_set_output_policy(7) == -1 and b'odbox_set_output_policy' in lib.odbox_last_error()
+    assert lib.odbox_set_output_policy(2) == 0 and lib.odbox_set_output_policy(0) == 2
     # empty problems are successes, decided before any pointer is looked at
     assert lib.odbox_anchor_tile(None, 9, 0, 4, 8.0, None, None) == 0
     assert lib.odbox_clip_boxes(None, 0, 8.0, 8.0, None, None) == 0

@@ -268,3 +268,23 @@ def test_streaming_variant_with_off_grid_tiles():
     reg = cpu(got['regression'])
     np.testing.assert_array_equal(reg[..., 4], ref['regression'][..., 4])
     np.testing.assert_allclose(reg[..., :4], ref['regression'][..., :4], rtol=1e-5, atol=0)
+
+
+def test_output_policy_changes_no_bit():
+    """odbox_set_output_policy only picks the store path (through / around the caches, 256- or 64-anchor tiles)."""
+    anchors = O.yolo_shaped_anchors(416)
+    gt, lab = workloads.match_inputs(2, batch=6, pad_to=24)
+    outs = {}
+    try:
+        for pol in ('auto', 'cache', 'stream'):
+            A.set_output_policy(pol)
+            outs[pol] = A.match_encode(anchors, (416, 416), gt, lab, 80, dense=True, compact=True, gt_best=True)
+    finally:
+        assert A.set_output_policy('auto') == 'stream'
+    ref = c_oracle.match_encode(anchors, (416, 416), gt, lab, 80, threads=4)
+    np.testing.assert_array_equal(cpu(outs['stream']['labels']), ref['labels'])
+    for pol in ('cache', 'stream'):
+        for k in outs['auto']:
+            assert torch.equal(outs['auto'][k], outs[pol][k]), (pol, k)
+    with pytest.raises(ValueError):
+        A.set_output_policy('fast')

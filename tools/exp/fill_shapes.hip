@@ -95,6 +95,19 @@ __global__ __launch_bounds__(256) void fill_sweep_jitter(v4f *p, size_t nvec, ui
     }
 }
 
+// H: bigger blocks on proportionally bigger chunks (NT: nontemporal stores): BS threads write BS/256 tiles
+template <int BS, bool NT>
+__global__ __launch_bounds__(BS) void fill_big_block(v4f *p, uint32_t per_block, size_t nvec)
+{
+    const size_t base = (size_t)blockIdx.x * per_block;
+    const v4f z = {0, 0, 0, 0};
+    for (uint32_t v = threadIdx.x; v < per_block; v += BS)
+        if (base + v < nvec) {
+            if (NT) __builtin_nontemporal_store(z, p + base + v);
+            else p[base + v] = z;
+        }
+}
+
 template <typename F>
 static float timed(F launch_, hipStream_t st)
 {
@@ -149,6 +162,17 @@ int main(int argc, char **argv)
             printf("   burn %u fixed %.2f us, random %.2f us", burn, timed([&] { fill_sweep_jitter<0><<<g, 256, 0, st>>>(p, nvec, 20, burn); }, st),
                    timed([&] { fill_sweep_jitter<1><<<g, 256, 0, st>>>(p, nvec, 20, burn); }, st));
         printf("\n");
+    }
+    {
+        const uint32_t pb2 = per_block * 2, pb4 = per_block * 4, pbh = per_block / 2, pbq = per_block / 4;
+        printf("H 64 thr x 1/4 tile %.2f us  nt %.2f us\n", timed([&] { fill_big_block<64, false><<<(uint32_t)((nvec + pbq - 1) / pbq), 64, 0, st>>>(p, pbq, nvec); }, st),
+               timed([&] { fill_big_block<64, true><<<(uint32_t)((nvec + pbq - 1) / pbq), 64, 0, st>>>(p, pbq, nvec); }, st));
+        printf("H 128 thr x 1/2 tile %.2f us  nt %.2f us\n", timed([&] { fill_big_block<128, false><<<(uint32_t)((nvec + pbh - 1) / pbh), 128, 0, st>>>(p, pbh, nvec); }, st),
+               timed([&] { fill_big_block<128, true><<<(uint32_t)((nvec + pbh - 1) / pbh), 128, 0, st>>>(p, pbh, nvec); }, st));
+        printf("H 512 thr x 2 tiles %.2f us  nt %.2f us\n", timed([&] { fill_big_block<512, false><<<(uint32_t)((nvec + pb2 - 1) / pb2), 512, 0, st>>>(p, pb2, nvec); }, st),
+               timed([&] { fill_big_block<512, true><<<(uint32_t)((nvec + pb2 - 1) / pb2), 512, 0, st>>>(p, pb2, nvec); }, st));
+        printf("H 1024 thr x 4 tiles %.2f us  nt %.2f us\n", timed([&] { fill_big_block<1024, false><<<(uint32_t)((nvec + pb4 - 1) / pb4), 1024, 0, st>>>(p, pb4, nvec); }, st),
+               timed([&] { fill_big_block<1024, true><<<(uint32_t)((nvec + pb4 - 1) / pb4), 1024, 0, st>>>(p, pb4, nvec); }, st));
     }
     printf("C 64 B per thread (tile)  %.2f us\n", timed([&] { fill_thread64<<<blocks, 256, 0, st>>>(p, per_block, nvec); }, st));
     printf("D sc1                     %.2f us\n", timed([&] { fill_block_chunk_asm<0><<<blocks, 256, 0, st>>>(p, per_block, nvec); }, st));
