@@ -113,6 +113,10 @@ constexpr int ZERO_LEAD = ODBOX_ZERO_LEAD;
 #endif
 constexpr int ME_TILE_STREAM = ODBOX_ME_TILE_STREAM;      // match_encode with a dense output far beyond the Infinity Cache
 constexpr int ME_GCHUNK = 512;
+#ifndef ODBOX_FAST_ROWS
+#define ODBOX_FAST_ROWS 4                  // GT rows per step of the division-free matcher loop
+#endif
+constexpr int FAST_ROWS = ODBOX_FAST_ROWS;
 
 // Phases 1 and 2 of the matcher for the calling thread's anchor n0 + threadIdx.x of image b:
 // anchors.py:215-274 (argmax IoU, thresholds), :178-184 (out-of-image), :187-194 (label).
@@ -213,6 +217,7 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
         const bool can_skip_zero = wmin_area >= 0.0f;      // false also for NaN
         // this wave's work list: 64 GT rows per step, one per lane, order preserved
         uint32_t nlist = 0;
+        uint64_t odd_rows = 0ull;                          // listed rows whose area is negative (or NaN)
         for (int gs = 0; gs < cnt; gs += WAVE) {
             const int g = gs + (int)lane;
             bool is_pad = false, is_zero = false;
@@ -225,6 +230,7 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
             }
             const bool keep = g < cnt && !is_pad && !is_zero;
             const uint64_t mk = __ballot(keep), mz = __ballot(is_zero), mp = __ballot(is_pad);
+            odd_rows |= __ballot(keep && !(s_ga[min(g, cnt - 1)].x >= 0.0f));
             if (keep) s_list[wave][nlist + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)g;
             nlist += (uint32_t)__popcll(mk);
             if (first_zero < 0 && mz != 0ull) first_zero = g0 + gs + __ffsll((unsigned long long)mz) - 1;
@@ -233,6 +239,74 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // ---- the usual case, division-free: every area in play is >= 0, so every IoU is >= +0 ----------
+        // The correctly rounded division is 13 of the ~29 issue cycles of a pair, and all the argmax needs
+        // from it is "is this row's quotient greater than the best so far".  q = i * rcp(u) is within
+        // 2^-22 of the true ratio (v_rcp_f32: 1 ulp), the rounded quotients within 2^-24: two rows whose q
+        // differ by more than 2^-19 relative compare the same way as their exact quotients, and only a
+        // row inside that band of the running best (a tie, or next to one: practically never) takes the
+        // exact IEEE divisions, of both.  i == 0 is the exact quotient +0 and never beats a best >= 0
+        // (strict >, first maximum wins).  The best row's exact IoU is computed once, after the loop.
+        // Same decisions as the exact loop below, row by row, hence the same argmax and the same value
+        // (tests/test_gpu_match.py::test_ties_and_near_ties_in_the_division_free_matcher).
+        if (!GTBEST && can_skip_zero && odd_rows == 0ull && nlist != 0u) {
+            constexpr float BAND_HI = 1.0f + 0x1p-19f, BAND_LO = 1.0f - 0x1p-19f;
+            auto exact_iou = [&](int row) {
+                const float4 bb = row >= g0 ? s_gt[row - g0] : gtb[row];
+                return pair_iou(a, a_area, bb, (bb.w - bb.y) * (bb.z - bb.x));
+            };
+            // best so far as an approximate quotient: -inf = none yet, 0 = an exact zero
+            float qb = best_iou;
+            // R rows at a time: their LDS reads and quotients are independent, only the short
+            // compare / select chain is serial; one ballot per group asks whether any lane met a band row
+            auto rows = [&](uint32_t k, auto rc) {
+                constexpr int R = decltype(rc)::value;
+                int g[R];
+                float ia[R], ua[R], q[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) g[r] = s_list[wave][k + r];
+                // (two rows per v_pk_add_f32 / v_pk_mul_f32 were tried for the subtractions, products and sums: same-box
+                // A/B on configs[3] 352-358 us packed against 340-346 us plain -- the register pairing costs more moves
+                // than the packing saves)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float4 gb = s_gt[g[r]];
+                    const float g_area = s_ga[g[r]].x;
+                    const float ix0 = fmaxf(a.x, gb.x), ix1 = fminf(a.z, gb.z);
+                    const float iy0 = fmaxf(a.y, gb.y), iy1 = fminf(a.w, gb.w);
+                    ia[r] = fmaxf(ix1 - ix0, 0.0f) * fmaxf(iy1 - iy0, 0.0f);
+                    ua[r] = ((a_area + g_area) - ia[r]) + 1e-8f;                         // bndbox.py:289, > 0 here
+                    q[r] = ia[r] * __builtin_amdgcn_rcpf(ua[r]);
+                }
+                const float qb0 = qb;
+                const int best0 = best;
+                bool any_band = false;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const bool take = q[r] * BAND_LO > qb;
+                    // (strict: q == 0 against a best of exactly 0 is a plain tie, not a band case -- and the band is
+                    // eight times wider than the error of q, so its edge can stay out)
+                    any_band = any_band || (!take && q[r] * BAND_HI > qb);
+                    qb = take ? q[r] : qb;
+                    best = take ? g0 + g[r] : best;
+                }
+                if (__ballot(any_band) != 0ull) {                  // wave-uniform, practically never: these rows again, exactly
+                    float vb = qb0 == -INFINITY ? qb0 : exact_iou(best0);
+                    best = best0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const float v = ia[r] / ua[r];
+                        if (v > vb) { vb = v; best = g0 + g[r]; }
+                    }
+                    qb = vb;
+                }
+            };
+            uint32_t k = 0;
+            for (; k + FAST_ROWS <= nlist; k += FAST_ROWS) rows(k, std::integral_constant<int, FAST_ROWS>{});
+            for (; k < nlist; ++k) rows(k, std::integral_constant<int, 1>{});
+            best_iou = exact_iou(best);
+            continue;
+        }
 #pragma unroll 2
         for (uint32_t k = 0; k < nlist; ++k) {
             const int g = s_list[wave][k];

@@ -288,3 +288,40 @@ def test_output_policy_changes_no_bit():
             assert torch.equal(outs['auto'][k], outs[pol][k]), (pol, k)
     with pytest.raises(ValueError):
         A.set_output_policy('fast')
+
+
+def test_ties_and_near_ties_in_the_division_free_matcher():
+    """The matcher compares i * rcp(u) and takes the exact IEEE divisions only for a row within 2^-19 of the
+    running best.  Rows that tie exactly (duplicates: the FIRST must win), rows one or a few ulps of a
+    coordinate apart (IoU values 0 .. a few ulps apart, in both orders) and rows that differ clearly
+    must give the oracle's argmax and its max IoU bit for bit."""
+    rng = np.random.default_rng(2024)
+    anchors = O.generate_anchors(256)
+    F = np.float32
+    rows = []
+    for _ in range(6):
+        b0 = workloads.gt_boxes(rng, 256, 1, 3)[0][0]
+        up = b0.copy(); up[2] = np.nextafter(up[2], F(1e9))              # one ulp wider
+        dn = b0.copy(); dn[3] = np.nextafter(dn[3], F(-1e9))             # one ulp shorter
+        far = b0.copy(); far[2] = np.nextafter(np.nextafter(np.nextafter(far[2], F(1e9)), F(1e9)), F(1e9))
+        sh = b0 + F(2.0 ** -12)                                          # shifted by a sub-pixel amount
+        rows += [b0, up, b0, dn, far, sh, dn, up]
+    gt = np.stack([np.stack(rows), np.stack(rows[::-1]), np.stack(rows[3:] + rows[:3])]).astype(F)
+    lab = (np.arange(gt.shape[0] * gt.shape[1]).reshape(gt.shape[:2]) % 3).astype(np.int32)
+    got = A.match_encode(anchors, (256, 256), gt, lab, 3, dense=False, compact=True)
+    ref = c_oracle.match_encode(anchors, (256, 256), gt, lab, 3, threads=4, dense=False)
+    np.testing.assert_array_equal(cpu(got['match_idx']), ref['match_idx'])
+    np.testing.assert_array_equal(cpu(got['state']), ref['state'])
+    np.testing.assert_array_equal(cpu(got['max_iou']).view(np.uint32), ref['max_iou'].view(np.uint32))
+    # the planted rows really are ties / near-ties for many anchors: the two best IoUs of an anchor are within 4 ulps
+    iou = O.bbox_overlap(np.broadcast_to(anchors, (3,) + anchors.shape), gt)
+    top2 = np.sort(iou, axis=2)[:, :, -2:]
+    close = (top2[..., 1] > 0) & (np.abs(top2[..., 1].view(np.int32) - top2[..., 0].view(np.int32)) <= 4)
+    assert close.sum() > 1000
+    # more rows than one LDS chunk, ties across the chunk boundary
+    big = np.concatenate([gt[:1, :40]] * 14, axis=1)[:, :530]
+    lab2 = np.zeros(big.shape[:2], np.int32)
+    got = A.match_encode(anchors, (256, 256), big, lab2, 1, dense=False, compact=True)
+    ref = c_oracle.match_encode(anchors, (256, 256), big, lab2, 1, threads=4, dense=False)
+    np.testing.assert_array_equal(cpu(got['match_idx']), ref['match_idx'])
+    np.testing.assert_array_equal(cpu(got['max_iou']).view(np.uint32), ref['max_iou'].view(np.uint32))

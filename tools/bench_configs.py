@@ -17,7 +17,6 @@ sys.path.insert(0, ROOT)
 from object_detection_amd import _lib, anchors as A, bndbox as BB, workloads  # noqa: E402
 
 HBM = 8000.0
-VALU_OPS = 39.3e12          # 256 CU x 64 lanes x 2.4 GHz, non-packed, no FMA
 
 
 def event_time(fn, iters, warm=5):
@@ -79,9 +78,9 @@ def main():
         byts = B * workloads.match_bytes_per_image(N, G, C)
         row = dict(cfg=cfg, B=B, N=N, G=G, C=C, us=t * 1e6, img_s=B / t, GBs=byts / t / 1e9, frac_hbm=byts / t / 1e9 / HBM)
         if cfg == 4:
-            ops = 16.0 * N * G * B
-            row['Tops'] = ops / t / 1e12
-            row['frac_valu_nonpacked'] = ops / t / VALU_OPS
+            # VALU-bound.  No "pairs / peak rate" fraction: the kernel proves most pairs zero without evaluating
+            # them, so that ratio exceeds 1; the SQ counters (tools/pmc_cfg.sh 4) say how busy the VALUs are
+            row['bound'] = 'valu (see profiles/pmc_traffic.json: match_encode_cfg3_valu_busy)'
         rows.append(row)
         if cfg == 2:
             # the optional compact-output mode (match index, state, 4 offsets + state column =
