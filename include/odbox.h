@@ -301,6 +301,33 @@ int odbox_restore_boxes(const float *boxes /*[B,R,4]*/, const float *scores /*[B
                         const int32_t *orig_hw /*[B,2]*/, int B, int R, int image_size,
                         double *out_boxes /*[B,R,4] f64*/, int32_t *out_count /*[B]*/, void *stream);
 
+/* ---- legacy / offline IoU conventions, NumPy float64 arithmetic ---- */
+
+/* mode 0: coco.py:169-191 calc_iou(box, boxes, area) for K boxes at once -- boxes_a [K,4] and
+ * boxes_b [N,4] in (cx, cy, h, w) layout, area_b [N] = np_anchor_areas (an input, not recomputed);
+ * mode 1: calculate_metrics.py:22-45 calc_ious(pred_boxes, true_box) -- boxes_a [K,4] true boxes and
+ * boxes_b [N,4] predictions, both xyxy, area_b ignored.  Both add one pixel to the intersection's
+ * width and height and none to the areas (so an IoU can exceed 1), in float64 with the reference's
+ * association.  out_iou [K,N]. */
+int odbox_legacy_iou(const double *boxes_a /*[K,4]*/, const double *boxes_b /*[N,4]*/,
+                     const double *area_b /*[N], mode 0*/, int K, int N, int mode,
+                     double *out_iou /*[K,N]*/, void *stream);
+
+/* coco.py:379-441, the sequential per-GT matcher of COCO_Iterable.process_image, for B images:
+ * anchors [N,4] (cx, cy, h, w) float64 with their areas [N]; gt_xywh [B,G,4] rows of (x0, y0, w, h)
+ * visited in order, rows with w <= 3 or h <= 3 skipped (:418; -1 padding rows fall under it);
+ * gt_labels [B,G] = the converted category of each row (self.cats[cat_id]).  An anchor takes a row's
+ * box (cx, cy, h, w) and label when iou > iou_thr (0.5 in the reference) and iou > its running
+ * maximum, which is kept ROUNDED to float32 like the reference's max_ious array.
+ * out_boxes [B,N,4] = true_bboxes (the anchor itself where nothing matched), out_labels [B,N] =
+ * true_labels as float64 (0 = nothing), out_max_iou [B,N] float32 (may be NULL), out_label_sum [B]
+ * = true_labels.sum() per image (may be NULL; 0 is the reference's "there are no true labels"). */
+int odbox_legacy_match(const double *anchors_cxcyhw /*[N,4]*/, const double *anchor_areas /*[N]*/,
+                       const double *gt_xywh /*[B,G,4]*/, const int32_t *gt_labels /*[B,G]*/,
+                       int B, int N, int G, double iou_thr, double *out_boxes /*[B,N,4]*/,
+                       double *out_labels /*[B,N]*/, float *out_max_iou /*[B,N]*/,
+                       double *out_label_sum /*[B]*/, void *stream);
+
 /* ---- multi-GPU plumbing (the reference has no counterpart) ---- */
 
 /* The fixed-size detection records that ONE all-gather moves between ranks: n = images * max_ret

@@ -60,6 +60,8 @@ SIGNATURES = {
     'odbox_restore_boxes': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'odbox_gt_prepare_xywh': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp]),
     'odbox_gt_prepare_poly': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp]),
+    'odbox_legacy_iou': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    'odbox_legacy_match': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, ctypes.c_double, _vp, _vp, _vp, _vp, _vp]),
 }
 
 

@@ -535,9 +535,185 @@ __global__ __launch_bounds__(256) void unpack_records_kernel(const float *__rest
     labels[i] = __float_as_int(r[5]);
 }
 
+// ------------------------------------------------------------------------------------------
+// the reference's legacy / offline IoU conventions, NumPy float64 arithmetic.
+//   mode 0  coco.py:169-191 calc_iou: (cx, cy, h, w) boxes, +1 pixel on the intersection's sides only,
+//           the second operand's area handed in (np_anchor_areas);
+//   mode 1  calculate_metrics.py:22-45 calc_ious: xyxy, the same +1, areas from the corners.
+// Same association as the reference: w = (xx1 - xx0) + 1, union = (area_a + area_b) - inter.
+// np.maximum(0, x) is fmax(0, x) for the finite values of the contract.
+// ------------------------------------------------------------------------------------------
+struct LegacyEdges {
+    double x0, x1, y0, y1, area;
+};
+
+template <int MODE>
+__device__ __forceinline__ LegacyEdges legacy_edges(const double *__restrict__ b, const double *__restrict__ area_in)
+{
+    LegacyEdges e;
+    if (MODE == 0) {
+        const double hw = b[3] / 2, hh = b[2] / 2;
+        e.x0 = b[0] - hw; e.x1 = b[0] + hw;
+        e.y0 = b[1] - hh; e.y1 = b[1] + hh;
+        e.area = area_in ? *area_in : b[2] * b[3];          // box[2] * box[3] for the first operand
+    } else {
+        e.x0 = b[0]; e.y0 = b[1]; e.x1 = b[2]; e.y1 = b[3];
+        e.area = (b[2] - b[0]) * (b[3] - b[1]);
+    }
+    return e;
+}
+
+__device__ __forceinline__ double legacy_ovr(const LegacyEdges &a, const LegacyEdges &b)
+{
+    const double w = fmax(0.0, (fmin(a.x1, b.x1) - fmax(a.x0, b.x0)) + 1.0);
+    const double h = fmax(0.0, (fmin(a.y1, b.y1) - fmax(a.y0, b.y0)) + 1.0);
+    const double inter = w * h;
+    return inter / ((a.area + b.area) - inter);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void legacy_iou_kernel(const double *__restrict__ boxes_a, const double *__restrict__ boxes_b,
+                                                         const double *__restrict__ area_b, uint32_t K, uint32_t N,
+                                                         double *__restrict__ out)
+{
+    const uint32_t n = blockIdx.x * 256u + threadIdx.x;
+    if (n >= N) return;
+    const LegacyEdges b = legacy_edges<MODE>(boxes_b + (size_t)n * 4, MODE == 0 ? area_b + n : nullptr);
+    for (uint32_t k = blockIdx.y; k < K; k += gridDim.y) {
+        const LegacyEdges a = legacy_edges<MODE>(boxes_a + (size_t)k * 4, nullptr);     // wave-uniform: scalar loads
+        out[(size_t)k * N + n] = legacy_ovr(a, b);
+    }
+}
+
+// coco.py:379-441, the sequential per-GT matcher, one thread per (image, anchor): the GT rows are
+// visited in order; an anchor is (re)assigned when iou > thr and iou > its running maximum, which the
+// reference keeps in a float32 array (:379) -- so the maximum is stored ROUNDED and widened again for
+// the next comparison, and that is reproduced here.  Rows with w <= 3 or h <= 3 are skipped (:418);
+// the library's -1 padding rows fall under that rule.
+constexpr int LEGACY_GT_CHUNK = 256;
+
+__global__ __launch_bounds__(256) void legacy_match_kernel(const double *__restrict__ anchors, const double *__restrict__ areas,
+                                                           const double *__restrict__ gt_xywh, const int32_t *__restrict__ gt_labels,
+                                                           uint32_t N, uint32_t G, double thr, double *__restrict__ out_boxes,
+                                                           double *__restrict__ out_labels, float *__restrict__ out_max_iou,
+                                                           double *__restrict__ out_label_sum)
+{
+    __shared__ double s_gt[LEGACY_GT_CHUNK][4];      // (cx, cy, h, w) of the rows that pass the size filter
+    __shared__ double s_lab[LEGACY_GT_CHUNK];
+    __shared__ int s_n;
+    __shared__ double s_sum[4];
+    const uint32_t b = blockIdx.y, n = blockIdx.x * 256u + threadIdx.x;
+    const bool live = n < N;
+    double box[4] = {0.0, 0.0, 0.0, 0.0}, label = 0.0;
+    float best = 0.0f;
+    LegacyEdges an{};
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) box[q] = anchors[(size_t)n * 4 + q];                // true_bboxes = anchors.copy()
+        an = legacy_edges<0>(box, areas + n);
+    }
+    for (uint32_t g0 = 0; g0 < G; g0 += LEGACY_GT_CHUNK) {
+        __syncthreads();
+        if (threadIdx.x == 0) {                      // order-preserving compaction of the chunk's usable rows
+            int cnt = 0;
+            const uint32_t g1 = min(G, g0 + (uint32_t)LEGACY_GT_CHUNK);
+            for (uint32_t g = g0; g < g1; ++g) {
+                const double *r = gt_xywh + ((size_t)b * G + g) * 4;
+                const double x0 = r[0], y0 = r[1], w = r[2], h = r[3];
+                if (w <= 3.0 || h <= 3.0) continue;
+                s_gt[cnt][0] = x0 + w / 2;           // :424-427
+                s_gt[cnt][1] = y0 + h / 2;
+                s_gt[cnt][2] = h;
+                s_gt[cnt][3] = w;
+                s_lab[cnt] = (double)gt_labels[(size_t)b * G + g];
+                ++cnt;
+            }
+            s_n = cnt;
+        }
+        __syncthreads();
+        const int cnt = s_n;
+        if (live)
+            for (int g = 0; g < cnt; ++g) {
+                const LegacyEdges e = legacy_edges<0>(s_gt[g], nullptr);
+                const double iou = legacy_ovr(e, an);
+                if (iou > thr && iou > (double)best) {                                   // :390-392
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) box[q] = s_gt[g][q];
+                    label = s_lab[g];
+                    best = (float)iou;                                                   // :413 into the float32 array
+                }
+            }
+    }
+    if (live) {
+        const size_t o = (size_t)b * N + n;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out_boxes[o * 4 + q] = box[q];
+        out_labels[o] = label;
+        if (out_max_iou) out_max_iou[o] = best;
+    }
+    if (out_label_sum) {                             // true_labels.sum() of :439 (labels are integers: exact in any order)
+        double s = live ? label : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if ((threadIdx.x & 63u) == 0) s_sum[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double t = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+            if (t != 0.0) atomicAdd(out_label_sum + b, t);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void zero_f64_kernel(double *__restrict__ p, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) p[i] = 0.0;
+}
+
 }  // namespace
 
 extern "C" {
+
+int odbox_legacy_iou(const double *boxes_a, const double *boxes_b, const double *area_b, int K, int N, int mode,
+                     double *out_iou, void *stream)
+{
+    if (K < 0 || N < 0) return fail(ODBOX_EINVAL, "odbox_legacy_iou: negative shape K=%d N=%d", K, N);
+    if (mode != 0 && mode != 1) return fail(ODBOX_EINVAL, "odbox_legacy_iou: mode must be 0 (cx,cy,h,w) or 1 (xyxy)");
+    if (K == 0 || N == 0) return 0;
+    if (!boxes_a || !boxes_b || !out_iou || (mode == 0 && !area_b)) return fail(ODBOX_EINVAL, "odbox_legacy_iou: NULL pointer");
+    if (((uintptr_t)boxes_a | (uintptr_t)boxes_b | (uintptr_t)area_b | (uintptr_t)out_iou) & 7u)
+        return fail(ODBOX_EINVAL, "odbox_legacy_iou: tensors must be 8-byte aligned");
+    const dim3 grid(((uint32_t)N + 255u) / 256u, (uint32_t)(K < 1024 ? K : 1024)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0)
+        hipLaunchKernelGGL(legacy_iou_kernel<0>, grid, block, 0, st, boxes_a, boxes_b, area_b, (uint32_t)K, (uint32_t)N, out_iou);
+    else
+        hipLaunchKernelGGL(legacy_iou_kernel<1>, grid, block, 0, st, boxes_a, boxes_b, area_b, (uint32_t)K, (uint32_t)N, out_iou);
+    return launch_status("odbox_legacy_iou");
+}
+
+int odbox_legacy_match(const double *anchors_cxcyhw, const double *anchor_areas, const double *gt_xywh,
+                       const int32_t *gt_labels, int B, int N, int G, double iou_thr, double *out_boxes,
+                       double *out_labels, float *out_max_iou, double *out_label_sum, void *stream)
+{
+    if (B < 0 || N < 0 || G < 0) return fail(ODBOX_EINVAL, "odbox_legacy_match: negative shape B=%d N=%d G=%d", B, N, G);
+    if (B == 0 || N == 0) return 0;
+    if (B > 65535) return fail(ODBOX_EINVAL, "odbox_legacy_match: B=%d over the limit of 65535", B);
+    if (!anchors_cxcyhw || !anchor_areas || !out_boxes || !out_labels || (G > 0 && (!gt_xywh || !gt_labels)))
+        return fail(ODBOX_EINVAL, "odbox_legacy_match: NULL pointer");
+    if (((uintptr_t)anchors_cxcyhw | (uintptr_t)anchor_areas | (uintptr_t)gt_xywh | (uintptr_t)out_boxes |
+         (uintptr_t)out_labels | (uintptr_t)out_label_sum) & 7u)
+        return fail(ODBOX_EINVAL, "odbox_legacy_match: fp64 tensors must be 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (out_label_sum) {
+        hipLaunchKernelGGL(zero_f64_kernel, dim3(((uint32_t)B + 255u) / 256u), dim3(256), 0, st, out_label_sum, (uint32_t)B);
+        if (int rc = launch_status("odbox_legacy_match (zero)")) return rc;
+    }
+    hipLaunchKernelGGL(legacy_match_kernel, dim3(((uint32_t)N + 255u) / 256u, (uint32_t)B), dim3(256), 0, st, anchors_cxcyhw,
+                       anchor_areas, gt_xywh, gt_labels, (uint32_t)N, (uint32_t)G, iou_thr, out_boxes, out_labels, out_max_iou,
+                       out_label_sum);
+    return launch_status("odbox_legacy_match");
+}
 
 int odbox_gt_prepare_xywh(const float *boxes_xywh, const int32_t *labels, const int32_t *row_offsets, int rows,
                           const float *orig_hw, int B, int max_items, float image_size, int half_round, int mode,

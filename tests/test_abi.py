@@ -192,6 +192,11 @@ def test_every_entry_rejects_bad_arguments_without_touching_the_gpu(lib):
         ('odbox_restore_boxes', (p, p, p, 2, 4, 0, p, p, None), -1),                                                             # image_size
         ('odbox_gt_prepare_poly', (p, p, p, 8, p, 2, 4, 512.0, 0, 7, p, p, None), -1),                                              # mode
         ('odbox_gt_prepare_xywh', (p, p, p, 8, p, 2, 4, 0.0, 0, 0, p, p, None), -1),                                                # image_size
+        ('odbox_legacy_iou', (p, p, None, 2, 4, 0, p, None), -1),                                                                # mode 0 needs the areas
+        ('odbox_legacy_iou', (p, p, p, 2, 4, 3, p, None), -1),                                                                   # mode
+        ('odbox_legacy_iou', (p, odd, p, 2, 4, 1, p, None), -1),                                                                 # alignment
+        ('odbox_legacy_match', (p, p, None, p, 1, 4, 2, 0.5, p, p, None, None, None), -1),                                       # GT rows NULL with G > 0
+        ('odbox_legacy_match', (p, p, p, p, 70000, 4, 2, 0.5, p, p, None, None, None), -1),                                      # B over the grid limit
     ]
     for name, args, want in cases:
         rc = getattr(lib, name)(*args)
@@ -206,3 +211,5 @@ def test_every_entry_rejects_bad_arguments_without_touching_the_gpu(lib):
     assert lib.odbox_decode_nms(None, None, None, 0, 4, 2, 8.0, 8.0, 1, 0.3, 0.45, 100, 0, None, None, None, None, None, None, 0, None) == 0
     assert lib.odbox_coco_match(None, None, None, None, None, 0, 2, 2, 3, thr, 2, rng, 1, 100, None, None, None, None, None, None, 0, None) == 0
     assert lib.odbox_gt_prepare_xywh(None, None, None, 0, None, 0, 4, 512.0, 0, 0, None, None, None) == 0
+    assert lib.odbox_legacy_iou(None, None, None, 0, 4, 0, None, None) == 0
+    assert lib.odbox_legacy_match(None, None, None, None, 0, 4, 2, 0.5, None, None, None, None, None) == 0
