@@ -446,7 +446,11 @@ __device__ __forceinline__ void wave_sort_to_lds(const uint64_t *src, uint32_t n
 }
 
 constexpr int SORT_THREADS = 1024;
-constexpr uint32_t SORT_LDS_CAP = 16384;   // keys a block sorts in LDS (128 KiB); more: in global memory
+constexpr uint32_t SORT_LDS_CAP = 16384;   // keys cand_sort_kernel sorts in LDS (128 KiB); more: in global memory
+// The three kernels behind the scan (partition, NMS, finalize) keep their LDS under TAIL_LDS_RESERVE so that
+// they fit on a CU beside the resident scan waves of another stream's batch (the scan leaves that much free).
+constexpr size_t TAIL_LDS_RESERVE = 22 * 1024;
+constexpr uint32_t TAIL_SORT_CAP = 2048;   // keys the partition / finalize blocks sort in LDS (16 KiB); more: in global memory
 constexpr uint32_t NMS_SEG_LDS = 512;      // keys one NMS wave sorts by itself; bigger segments: block sort
 #ifndef ODBOX_NMS_COOP_MIN
 #define ODBOX_NMS_COOP_MIN 128
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
     if (!big) return;                                    // block-uniform
     if (tid == 0) big_flag[b] = 1;
     __syncthreads();                                     // scatter visible to the whole block
-    if (M <= SORT_LDS_CAP) {
+    if (M <= TAIL_SORT_CAP) {
         uint64_t *s_keys = reinterpret_cast<uint64_t *>(s_part);
         for (uint32_t i = tid; i < M; i += PART_THREADS) s_keys[i] = out[i];
         __syncthreads();
@@ -700,7 +704,8 @@ __device__ __forceinline__ void nms_wave_segment(
     int C, int do_clip, float hi_x, float hi_y, NmsThr thr, int max_ret, const uint64_t *__restrict__ cand_keys,
     uint32_t cand_stride, const int *__restrict__ seg_start, const int *__restrict__ big_flag,
     int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys, uint32_t fin_stride,
-    uint32_t total_segments, int waves_per_block, uint32_t per_wave_bytes, uint32_t sort_cap, bool coop_on, uint32_t dbg)
+    uint32_t total_segments, int waves_per_block, uint32_t per_wave_bytes, uint32_t sort_cap, bool coop_on, bool kept_alias,
+    uint32_t dbg)
 {
     ODBOX_NO_EXPERIMENTS(dbg);
     const uint32_t lane = threadIdx.x & 63u;
@@ -719,7 +724,10 @@ __device__ __forceinline__ void nms_wave_segment(
     unsigned char *mine = s_raw + (size_t)wave * per_wave_bytes;
     const int extra = max_ret > NMS_REG_KEPT ? max_ret - NMS_REG_KEPT : 0;
     uint64_t *s_sort = reinterpret_cast<uint64_t *>(mine);
-    uint64_t *s_key = s_sort + sort_cap;
+    // kept keys: behind the sort buffer, or ON it when kept_alias says the two are never live together (with the
+    // cooperative blocks on, a wave that sorts takes the lean path, which keeps its kept set in registers, and the
+    // general path below only ever sees presorted segments, which do not use s_sort)
+    uint64_t *s_key = kept_alias ? s_sort : s_sort + sort_cap;
     float4 *s_box = reinterpret_cast<float4 *>(s_key + ((max_ret + 1) & ~1)) - NMS_REG_KEPT;   // indexed by kept
     float *s_area = reinterpret_cast<float *>(s_box + NMS_REG_KEPT + extra) - NMS_REG_KEPT;
 
@@ -924,7 +932,11 @@ __device__ __forceinline__ void nms_wave_segment(
 // the walk (1728 instructions per chunk whether rows survive or not: 40 us).  Greedy order, the TF
 // NonMaxSuppressionV3 test and the max_ret cut are those of the wave form: identical keep-list.
 // ------------------------------------------------------------------------------------------
-constexpr size_t COOP_LDS = (size_t)NMS_SEG_LDS * (8 + 8 + 16 + 4) + NMS_WAVES * 16 + 16;
+// LDS of a cooperative block: sorted keys, unsorted-then-kept keys, and TWO 64-box buffers -- only the boxes of the
+// chunk just resolved are ever read by other waves, so the owner publishes its 64 boxes at the end of its walk
+// (double buffered: the readers of chunk ch are done before the barrier that chunk ch+1 ends with).  10.9 KB
+// instead of 18.5 KB with all 512 boxes in LDS: two blocks fit beside the resident score-scan waves of another stream.
+constexpr size_t COOP_LDS = (size_t)NMS_SEG_LDS * (8 + 8) + 2 * WAVE * (16 + 4) + NMS_WAVES * 16 + 16;
 
 __device__ __forceinline__ void nms_coop_block(
     unsigned char *s_raw, uint32_t block, uint32_t nblocks, const float4 *__restrict__ anchors,
@@ -936,9 +948,9 @@ __device__ __forceinline__ void nms_coop_block(
     static_assert(NMS_WAVES * WAVE == (int)NMS_SEG_LDS, "one wave per 64-candidate chunk");
     uint64_t *s_key = reinterpret_cast<uint64_t *>(s_raw);                         // sorted keys
     uint64_t *s_kkey = s_key + NMS_SEG_LDS;                                        // unsorted keys, then kept keys
-    float4 *s_box = reinterpret_cast<float4 *>(s_kkey + NMS_SEG_LDS);
-    float *s_area = reinterpret_cast<float *>(s_box + NMS_SEG_LDS);
-    unsigned long long *s_keptmask = reinterpret_cast<unsigned long long *>(s_area + NMS_SEG_LDS);
+    float4 *s_box = reinterpret_cast<float4 *>(s_kkey + NMS_SEG_LDS);              // [2][WAVE] boxes of the last two chunks
+    float *s_area = reinterpret_cast<float *>(s_box + 2 * WAVE);                   // [2][WAVE]
+    unsigned long long *s_keptmask = reinterpret_cast<unsigned long long *>(s_area + 2 * WAVE);
     int *s_nkept = reinterpret_cast<int *>(s_keptmask + NMS_WAVES);
     int *s_base = s_nkept + NMS_WAVES;
 
@@ -976,9 +988,6 @@ __device__ __forceinline__ void nms_coop_block(
             pb = make_float4(fminf(v.x, v.z), fminf(v.y, v.w), fmaxf(v.x, v.z), fmaxf(v.y, v.w));
             pa = (pb.w - pb.y) * (pb.z - pb.x);
         }
-        s_box[tid] = pb;
-        s_area[tid] = pa;
-        __syncthreads();
 
         // (2) chunks in order
         bool dead = !vi;
@@ -1002,6 +1011,8 @@ __device__ __forceinline__ void nms_coop_block(
                     s_keptmask[ch] = keptmask;
                     s_nkept[ch] = kept;
                 }
+                s_box[(ch & 1u) * WAVE + lane] = pb;         // the chunk's boxes, for the waves of the later chunks
+                s_area[(ch & 1u) * WAVE + lane] = pa;
             }
             __syncthreads();
             kept_total = s_nkept[ch];
@@ -1010,8 +1021,8 @@ __device__ __forceinline__ void nms_coop_block(
                 const unsigned long long km0 = s_keptmask[ch];
                 const unsigned long long keptmask = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(km0 >> 32)) << 32) |
                                                     (unsigned int)__builtin_amdgcn_readfirstlane((int)km0);
-                const float4 jb = s_box[ch * WAVE + lane];
-                const float ja = s_area[ch * WAVE + lane];
+                const float4 jb = s_box[(ch & 1u) * WAVE + lane];
+                const float ja = s_area[(ch & 1u) * WAVE + lane];
                 bool hit = false, band = false;
                 for (unsigned long long km = keptmask; km != 0ull; km &= km - 1ull) {
                     const int j = __ffsll(km) - 1;
@@ -1056,7 +1067,8 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
     uint32_t cand_stride, const int *__restrict__ seg_start, const int *__restrict__ big_flag,
     const int *__restrict__ coop_count, const int *__restrict__ coop_list, uint32_t coop_blocks,
     int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys, uint32_t fin_stride,
-    uint32_t total_segments, int waves_per_block, uint32_t per_wave_bytes, uint32_t sort_cap, uint32_t dbg)
+    uint32_t total_segments, int waves_per_block, uint32_t per_wave_bytes, uint32_t sort_cap, uint32_t kept_alias,
+    uint32_t dbg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     ODBOX_NO_EXPERIMENTS(dbg);
@@ -1068,7 +1080,7 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
     else
         nms_wave_segment(s_raw, blockIdx.x - coop_blocks, anchors, rb, N, C, do_clip, hi_x, hi_y, thr, max_ret,
                          cand_keys, cand_stride, seg_start, big_flag, fin_count, fin_keys, fin_stride, total_segments,
-                         waves_per_block, per_wave_bytes, sort_cap, coop_blocks != 0, dbg);
+                         waves_per_block, per_wave_bytes, sort_cap, coop_blocks != 0, kept_alias != 0, dbg);
 }
 
 // kernel 4: per image, order the kept detections like tf.math.top_k over the class-ordered
@@ -1114,7 +1126,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
     };
     if (out_count && tid == 0) out_count[b] = (int32_t)keep;
 
-    if ((uint32_t)max_ret <= FIN_CHUNK && n <= SORT_LDS_CAP) {
+    if ((uint32_t)max_ret <= FIN_CHUNK && n <= TAIL_SORT_CAP) {
         const uint32_t nchunks = (n + FIN_CHUNK - 1) / FIN_CHUNK;
         const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = FIN_THREADS / WAVE;
         for (uint32_t i = tid; i < nchunks * FIN_CHUNK; i += FIN_THREADS) s_keys[i] = i < n ? gk[i] : ~0ull;
@@ -1147,7 +1159,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
             __syncthreads();
         }
         emit(s_keys);
-    } else if (n <= SORT_LDS_CAP) {
+    } else if (n <= TAIL_SORT_CAP) {
         for (uint32_t i = tid; i < n; i += FIN_THREADS) s_keys[i] = gk[i];
         __syncthreads();
         sort_u64<true>(s_keys, n, tid, FIN_THREADS);
@@ -1318,14 +1330,27 @@ int launch_scan_inst(const float *scores, int B, int N, int C, const ScanGeom &g
         return fail(ODBOX_EINVAL, "odbox_decode_nms: C=%d needs %zu bytes of LDS per wave", C, lds);
     int per_cu = (int)((160 * 1024) / align_up(lds, 1024));
     per_cu = per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu);
+    // leave TAIL_LDS_RESERVE bytes of every CU's LDS to other kernels: the partition / NMS / finalize
+    // launches of ANOTHER batch (a second stream) then run beside this scan instead of behind it.
+    // Measured at config 5: the scan is as fast with 5 resident waves per CU as with 6.
+    while (per_cu > 2 && (size_t)per_cu * align_up(lds, 1024) + TAIL_LDS_RESERVE > 160 * 1024) --per_cu;
+    // ... and no more than that: the allocation of each wave is padded until what is left of the CU's LDS is too
+    // small for a scan wave of another stream.  Two scans side by side share the HBM rate, finish together and
+    // leave the memory system idle while both streams run their tail kernels (2 streams: 209 us per batch);
+    // with one scan at a time the other stream's tail kernels always have a scan to hide under.
+    size_t lds_alloc = lds;
+    if (!tuning_env("ODBOX_SCAN_NO_PAD")) {
+        const size_t pad_to = ((160 * 1024 - TAIL_LDS_RESERVE) / per_cu) & ~(size_t)1023;
+        if (pad_to > lds_alloc) lds_alloc = pad_to;
+    }
     if (const char *e = tuning_env("ODBOX_SCAN_WAVES_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;   // tuning aid
     uint32_t nq = SCAN_QUEUES, dbg = 0;
     if (const char *e = tuning_env("ODBOX_SCAN_QUEUES")) nq = atoi(e) > 0 && atoi(e) <= (int)SCAN_QUEUES ? atoi(e) : nq;
     if (const char *e = tuning_env("ODBOX_SCAN_DBG")) dbg = (uint32_t)atoi(e);
     const uint64_t resident = (uint64_t)device_cu_count() * per_cu;
     const uint32_t grid = (uint32_t)(total < resident ? total : resident);
-    if (int rc = allow_lds(score_scan_kernel<V, LL>, lds)) return rc;
-    hipLaunchKernelGGL((score_scan_kernel<V, LL>), dim3(grid), dim3(WAVE), lds, st, scores, N, C, g, score_thr,
+    if (int rc = allow_lds(score_scan_kernel<V, LL>, lds_alloc)) return rc;
+    hipLaunchKernelGGL((score_scan_kernel<V, LL>), dim3(grid), dim3(WAVE), lds_alloc, st, scores, N, C, g, score_thr,
                        (uint32_t)tiles, (uint32_t)total, tile_ticket, cand_count, cand_keys, cand_stride, nq, dbg);
     return launch_status("score_scan");
 }
@@ -1425,7 +1450,8 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
         nms_keys = keys_a;
     } else {
         size_t part_lds = (size_t)(C + PART_THREADS + 1) * sizeof(int);
-        if (part_lds < sort_lds) part_lds = sort_lds;       // the block may have to sort the whole list
+        const size_t part_sort = (size_t)(L.cand_stride < TAIL_SORT_CAP ? L.cand_stride : TAIL_SORT_CAP) * 8;
+        if (part_lds < part_sort) part_lds = part_sort;     // the block may have to sort the whole list
         if (int r2 = allow_lds(cand_partition_kernel, part_lds)) return r2;
         hipLaunchKernelGGL(cand_partition_kernel, dim3(B), dim3(PART_THREADS), part_lds, st, cand_count, keys_a, keys_b,
                            L.cand_stride, C, seg_start, big_flag, coop_count, coop_list);
@@ -1448,6 +1474,13 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
     const NmsThr nms_thr = {iou_thr, iou_thr * (1.0f - 0x1p-20f), iou_thr * (1.0f + 0x1p-20f)};
     // cooperative blocks need the full block; their list is only built by the partition kernel
     const uint32_t coop_blocks = (waves == NMS_WAVES && pre_nms_topk == 0) ? (uint32_t)(segs < ODBOX_COOP_BLOCKS ? segs : ODBOX_COOP_BLOCKS) : 0u;
+    uint32_t kept_alias = 0;
+#ifndef ODBOX_TUNING_HOOKS                                         // (the experiment switches can route a sorted segment to the general path)
+    if (coop_blocks) {                                             // sort buffer and kept keys are never live together: share
+        kept_alias = 1;
+        per_wave = align_up(kept_bytes > (size_t)NMS_COOP_MIN * 8 ? kept_bytes : (size_t)NMS_COOP_MIN * 8, 16);
+    }
+#endif
     size_t nms_lds = per_wave * waves;
     if (coop_blocks && nms_lds < COOP_LDS) nms_lds = COOP_LDS;
     const uint64_t nms_grid = (segs + waves - 1) / waves + coop_blocks;
@@ -1455,12 +1488,12 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
     hipLaunchKernelGGL(nms_kernel, dim3((uint32_t)nms_grid), dim3(waves * WAVE), nms_lds, st, (const float4 *)anchors,
                        (const float4 *)regress_or_boxes, N, C, do_clip, hi_x, hi_y, nms_thr, max_ret, nms_keys,
                        L.cand_stride, seg_start, big_flag, (const int *)coop_count, (const int *)coop_list, coop_blocks,
-                       fin_count, fin_keys, L.fin_stride, (uint32_t)segs, waves, (uint32_t)per_wave, sort_cap,
+                       fin_count, fin_keys, L.fin_stride, (uint32_t)segs, waves, (uint32_t)per_wave, sort_cap, kept_alias,
                        (uint32_t)(tuning_env("ODBOX_NMS_DBG") ? atoi(tuning_env("ODBOX_NMS_DBG")) : 0));
     if (int r3 = launch_status("nms")) return r3;
 
     // kernel 4: final order, top max_ret, zero padding
-    const size_t fin_lds = align_up((size_t)(L.fin_stride < SORT_LDS_CAP ? L.fin_stride : SORT_LDS_CAP), FIN_CHUNK) * 8;
+    const size_t fin_lds = align_up((size_t)(L.fin_stride < TAIL_SORT_CAP ? L.fin_stride : TAIL_SORT_CAP), FIN_CHUNK) * 8;
     if (int r4 = allow_lds(finalize_kernel, fin_lds)) return r4;
     hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(FIN_THREADS), fin_lds, st, (const float4 *)anchors,
                        (const float4 *)regress_or_boxes, N, do_clip, hi_x, hi_y, max_ret, fin_count, fin_keys,
