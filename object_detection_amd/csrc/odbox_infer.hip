@@ -458,18 +458,22 @@ constexpr uint32_t NMS_SEG_LDS = 512;      // keys one NMS wave sorts by itself;
 constexpr int NMS_COOP_MIN = ODBOX_NMS_COOP_MIN;          // segments above this (and <= NMS_SEG_LDS): nms_coop_kernel, one block each
 
 // kernel 2: counting sort of one image's candidate keys by class (LDS histogram -> scan ->
-// scatter); writes the class segment starts.  When one class holds more keys than an NMS wave
-// sorts on its own (NMS_SEG_LDS) the block also sorts the whole list -- it is grouped by class
-// already, so a full key sort puts every segment in visiting order -- and flags the image.
+// scatter); writes the class segment starts.  A class with more keys than an NMS block sorts on its
+// own (NMS_SEG_LDS) is put in visiting order here, segment by segment (in LDS up to TAIL_SORT_CAP keys,
+// in global memory beyond): the NMS kernel takes every segment above NMS_SEG_LDS as presorted.
 #ifndef ODBOX_PART_THREADS
 #define ODBOX_PART_THREADS 512
 #endif
 constexpr int PART_THREADS = ODBOX_PART_THREADS;
 
+__host__ __device__ inline size_t part_sort_offset(int C)      // byte offset of the sort buffer behind hist + scan scratch
+{
+    return ((size_t)(C + PART_THREADS + 1) * sizeof(int) + 15) & ~(size_t)15;
+}
+
 __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
     const int *__restrict__ cand_count, const uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out,
-    uint32_t cand_stride, int C, int *__restrict__ seg_start, int *__restrict__ big_flag,
-    int *__restrict__ coop_count, int *__restrict__ coop_list)
+    uint32_t cand_stride, int C, int *__restrict__ seg_start, int *__restrict__ coop_count, int *__restrict__ coop_list)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_part[];
     int *s_hist = reinterpret_cast<int *>(s_part);       // [C] counts -> cursors
@@ -523,20 +527,16 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
         const int cnt = s_hist[c];
         seg[c] = run;
         s_hist[c] = run;                 // becomes the scatter cursor
+        // segments of NMS_COOP_MIN < m <= NMS_SEG_LDS candidates go to the cooperative blocks of the NMS kernel
+        if (cnt > NMS_COOP_MIN && cnt <= (int)NMS_SEG_LDS) {
+            const uint32_t at = (uint32_t)atomicAdd(coop_count, 1);
+            if (at < gridDim.x * (uint32_t)C) coop_list[at] = (int)(b * (uint32_t)C + (uint32_t)c);
+        }
         run += cnt;
     }
     if (tid == 0) seg[C] = (int)M;
     const bool big = s_scan[PART_THREADS] != 0;
     __syncthreads();
-    // segments of NMS_COOP_MIN < m <= NMS_SEG_LDS candidates go to the cooperative blocks of the NMS kernel
-    if (!big)
-        for (int c = c0; c < c1; ++c) {
-            const int cnt = (c + 1 < C ? seg[c + 1] : (int)M) - seg[c];
-            if (cnt > NMS_COOP_MIN) {
-                const uint32_t at = (uint32_t)atomicAdd(coop_count, 1);
-                if (at < gridDim.x * (uint32_t)C) coop_list[at] = (int)(b * (uint32_t)C + (uint32_t)c);
-            }
-        }
     if (in_regs) {
 #pragma unroll
         for (int r = 0; r < PART_REG; ++r)
@@ -552,16 +552,22 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
         }
     }
     if (!big) return;                                    // block-uniform
-    if (tid == 0) big_flag[b] = 1;
-    __syncthreads();                                     // scatter visible to the whole block
-    if (M <= TAIL_SORT_CAP) {
-        uint64_t *s_keys = reinterpret_cast<uint64_t *>(s_part);
-        for (uint32_t i = tid; i < M; i += PART_THREADS) s_keys[i] = out[i];
-        __syncthreads();
-        sort_u64<true>(s_keys, M, tid, PART_THREADS);
-        for (uint32_t i = tid; i < M; i += PART_THREADS) out[i] = s_keys[i];
-    } else {
-        sort_u64<true>(out, M, tid, PART_THREADS);
+    __syncthreads();                                     // scatter visible to the whole block; s_hist[c] = end of segment c
+    uint64_t *s_keys = reinterpret_cast<uint64_t *>(s_part + part_sort_offset(C));
+    for (int c = 0; c < C; ++c) {                        // every test below is block-uniform
+        const uint32_t st = c > 0 ? min((uint32_t)s_hist[c - 1], M) : 0u;
+        const uint32_t en = min((uint32_t)s_hist[c], M);
+        if (en <= st || en - st <= NMS_SEG_LDS) continue;
+        const uint32_t m = en - st;
+        if (m <= TAIL_SORT_CAP) {
+            for (uint32_t i = tid; i < m; i += PART_THREADS) s_keys[i] = out[st + i];
+            __syncthreads();
+            sort_u64<true>(s_keys, m, tid, PART_THREADS);
+            for (uint32_t i = tid; i < m; i += PART_THREADS) out[st + i] = s_keys[i];
+            __syncthreads();
+        } else {
+            sort_u64<true>(out + st, m, tid, PART_THREADS);
+        }
     }
 }
 
@@ -732,7 +738,9 @@ __device__ __forceinline__ void nms_wave_segment(
     float *s_area = reinterpret_cast<float *>(s_box + NMS_REG_KEPT + extra) - NMS_REG_KEPT;
 
     const uint64_t *keys = cand_keys + (size_t)b * cand_stride + start;
-    const bool presorted = big_flag[b] != 0;
+    // in visiting order already: every segment of an image that went through cand_sort_kernel (the flag), and every
+    // segment longer than a block sorts itself (sorted by the partition kernel)
+    const bool presorted = big_flag[b] != 0 || m > NMS_SEG_LDS;
     if (coop_on && !presorted && m > (uint32_t)NMS_COOP_MIN) return;       // a cooperative block's segment
     uint64_t reg_key = ~0ull;
     const uint64_t *sorted = keys;
@@ -1098,7 +1106,7 @@ constexpr uint32_t FIN_CHUNK = 128;
 __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
     const float4 *__restrict__ anchors, const float4 *__restrict__ rb, int N, int do_clip, float hi_x,
     float hi_y, int max_ret, const int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys,
-    uint32_t fin_stride, float4 *__restrict__ out_boxes, float *__restrict__ out_scores,
+    uint32_t fin_stride, uint32_t lds_keys, float4 *__restrict__ out_boxes, float *__restrict__ out_scores,
     int32_t *__restrict__ out_labels, int32_t *__restrict__ out_keep, int32_t *__restrict__ out_count)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
@@ -1126,37 +1134,46 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
     };
     if (out_count && tid == 0) out_count[b] = (int32_t)keep;
 
-    if ((uint32_t)max_ret <= FIN_CHUNK && n <= TAIL_SORT_CAP) {
-        const uint32_t nchunks = (n + FIN_CHUNK - 1) / FIN_CHUNK;
+    if ((uint32_t)max_ret <= FIN_CHUNK) {
+        // the list goes through LDS in batches of lds_keys keys: the 128 best so far are carried in chunk 0
         const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = FIN_THREADS / WAVE;
-        for (uint32_t i = tid; i < nchunks * FIN_CHUNK; i += FIN_THREADS) s_keys[i] = i < n ? gk[i] : ~0ull;
-        __syncthreads();
-        for (uint32_t c = wave; c < nchunks; c += nwaves) {
-            uint64_t k[2];
-            uint64_t *ch = s_keys + c * FIN_CHUNK;
-            k[0] = ch[lane * 2];
-            k[1] = ch[lane * 2 + 1];
-            wave_sort_regs<2>(k, lane);
-            ch[lane * 2] = k[0];
-            ch[lane * 2 + 1] = k[1];
-        }
-        __syncthreads();
-        for (uint32_t stride = 1; stride < nchunks; stride <<= 1) {
-            for (uint32_t c = wave * 2 * stride; c + stride < nchunks; c += nwaves * 2 * stride) {
-                uint64_t *lo = s_keys + c * FIN_CHUNK;
-                const uint64_t *hi = s_keys + (c + stride) * FIN_CHUNK;
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < n || base == 0;) {
+            const uint32_t take = min(n - base, lds_keys - carry);
+            const uint32_t cnt = carry + take;
+            const uint32_t nchunks = (cnt + FIN_CHUNK - 1) / FIN_CHUNK;
+            for (uint32_t i = carry + tid; i < nchunks * FIN_CHUNK; i += FIN_THREADS) s_keys[i] = i < cnt ? gk[base + i - carry] : ~0ull;
+            __syncthreads();
+            for (uint32_t c = wave; c < nchunks; c += nwaves) {
                 uint64_t k[2];
-#pragma unroll
-                for (uint32_t s0 = 0; s0 < 2; ++s0) {
-                    const uint32_t e = lane * 2 + s0;
-                    const uint64_t x = lo[e], y = hi[FIN_CHUNK - 1 - e];
-                    k[s0] = x < y ? x : y;
-                }
-                wave_sort_regs<2, true>(k, lane);
-                lo[lane * 2] = k[0];
-                lo[lane * 2 + 1] = k[1];
+                uint64_t *ch = s_keys + c * FIN_CHUNK;
+                k[0] = ch[lane * 2];
+                k[1] = ch[lane * 2 + 1];
+                wave_sort_regs<2>(k, lane);
+                ch[lane * 2] = k[0];
+                ch[lane * 2 + 1] = k[1];
             }
             __syncthreads();
+            for (uint32_t stride = 1; stride < nchunks; stride <<= 1) {
+                for (uint32_t c = wave * 2 * stride; c + stride < nchunks; c += nwaves * 2 * stride) {
+                    uint64_t *lo = s_keys + c * FIN_CHUNK;
+                    const uint64_t *hi = s_keys + (c + stride) * FIN_CHUNK;
+                    uint64_t k[2];
+#pragma unroll
+                    for (uint32_t s0 = 0; s0 < 2; ++s0) {
+                        const uint32_t e = lane * 2 + s0;
+                        const uint64_t x = lo[e], y = hi[FIN_CHUNK - 1 - e];
+                        k[s0] = x < y ? x : y;
+                    }
+                    wave_sort_regs<2, true>(k, lane);
+                    lo[lane * 2] = k[0];
+                    lo[lane * 2 + 1] = k[1];
+                }
+                __syncthreads();
+            }
+            base += take;
+            carry = FIN_CHUNK;
+            if (base >= n) break;
         }
         emit(s_keys);
     } else if (n <= TAIL_SORT_CAP) {
@@ -1449,12 +1466,12 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
         if (int r2 = launch_status("cand_sort")) return r2;
         nms_keys = keys_a;
     } else {
-        size_t part_lds = (size_t)(C + PART_THREADS + 1) * sizeof(int);
-        const size_t part_sort = (size_t)(L.cand_stride < TAIL_SORT_CAP ? L.cand_stride : TAIL_SORT_CAP) * 8;
-        if (part_lds < part_sort) part_lds = part_sort;     // the block may have to sort the whole list
+        // hist + scan scratch, then room to sort one oversized class segment (only lists that can hold one need it)
+        const size_t part_sort = L.cand_stride > NMS_SEG_LDS ? (size_t)(L.cand_stride < TAIL_SORT_CAP ? L.cand_stride : TAIL_SORT_CAP) * 8 : 0;
+        const size_t part_lds = part_sort_offset(C) + part_sort;
         if (int r2 = allow_lds(cand_partition_kernel, part_lds)) return r2;
         hipLaunchKernelGGL(cand_partition_kernel, dim3(B), dim3(PART_THREADS), part_lds, st, cand_count, keys_a, keys_b,
-                           L.cand_stride, C, seg_start, big_flag, coop_count, coop_list);
+                           L.cand_stride, C, seg_start, coop_count, coop_list);
         if (int r2 = launch_status("cand_partition")) return r2;
         nms_keys = keys_b;
     }
@@ -1493,11 +1510,15 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
     if (int r3 = launch_status("nms")) return r3;
 
     // kernel 4: final order, top max_ret, zero padding
-    const size_t fin_lds = align_up((size_t)(L.fin_stride < TAIL_SORT_CAP ? L.fin_stride : TAIL_SORT_CAP), FIN_CHUNK) * 8;
+    // keys per LDS batch: a multiple of the 128-key chunk, at least two chunks (one carried + one new)
+    size_t fin_keys_lds = align_up((size_t)(L.fin_stride < TAIL_SORT_CAP ? L.fin_stride : TAIL_SORT_CAP), FIN_CHUNK);
+    if (fin_keys_lds < 2 * FIN_CHUNK) fin_keys_lds = 2 * FIN_CHUNK;
+    const size_t fin_lds = fin_keys_lds * 8;
     if (int r4 = allow_lds(finalize_kernel, fin_lds)) return r4;
     hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(FIN_THREADS), fin_lds, st, (const float4 *)anchors,
                        (const float4 *)regress_or_boxes, N, do_clip, hi_x, hi_y, max_ret, fin_count, fin_keys,
-                       L.fin_stride, (float4 *)out_boxes, out_scores, out_labels, out_keep_anchor, out_count);
+                       L.fin_stride, (uint32_t)fin_keys_lds, (float4 *)out_boxes, out_scores, out_labels, out_keep_anchor,
+                       out_count);
     return launch_status("finalize");
 }
 

@@ -237,6 +237,45 @@ def test_cooperative_block_with_mixed_segments_in_one_image():
     check(got, want)
 
 
+def test_oversized_class_beside_cooperative_and_small_ones():
+    """Segments above 512 candidates are sorted by the partition kernel one by one (in LDS up to 2048 keys, in
+    global memory beyond) and walked as presorted, while the other classes of the SAME image still take the
+    cooperative-block and single-wave paths."""
+    rng = np.random.default_rng(9)
+    N, C, B = 9000, 7, 3
+    anchors = O.tile_anchors(O.base_anchors(24, (1, 2, .5)), 32, 32, 8)[:N]
+    regress = np.clip(rng.normal(0, 0.5, (B, N, 4)), -2, 2).astype(F)
+    scores = rng.uniform(0, 0.2, (B, N, C)).astype(F)
+    for b in range(B):
+        perm = rng.permutation(N)
+        at = 0
+        for c, m in enumerate((300, 2500, 40, 513, 0, 1500, 129)):
+            idx = perm[at:at + m]
+            at += m
+            scores[b, idx, c] = (np.floor((0.3 + 0.7 * rng.uniform(size=m)) * 128) / 128).astype(F)      # many ties
+    for max_ret in (100, 300):
+        got = BB.decode_and_nms(anchors, regress, scores, (256, 256), max_ret=max_ret, return_keep=True)
+        want = c_oracle.decode_nms(anchors, regress, scores, (256, 256), max_ret=max_ret, threads=4)
+        check(got, want)
+
+
+def test_kept_list_longer_than_one_lds_batch_of_the_final_top_k():
+    """Many classes, few suppressions: C * max_ret kept detections per image go through the final top-k in several
+    LDS batches (the 128 best so far carried from batch to batch)."""
+    rng = np.random.default_rng(10)
+    N, C, B = 12000, 60, 2
+    anchors = O.tile_anchors(O.base_anchors(8, (1, 2, .5)), 37, 37, 16)[:N]          # small boxes far apart: little overlap
+    regress = np.clip(rng.normal(0, 0.1, (B, N, 4)), -0.5, 0.5).astype(F)
+    scores = rng.uniform(0, 0.2, (B, N, C)).astype(F)
+    for b in range(B):
+        idx = rng.choice(N, 7000, replace=False)
+        scores[b, idx, rng.integers(0, C, 7000)] = (np.floor((0.3 + 0.7 * rng.uniform(size=7000)) * 64) / 64).astype(F)
+    for max_ret in (100, 128, 5):
+        got = BB.decode_and_nms(anchors, regress, scores, (600, 600), max_ret=max_ret, return_keep=True)
+        want = c_oracle.decode_nms(anchors, regress, scores, (600, 600), max_ret=max_ret, threads=4)
+        check(got, want)
+
+
 @pytest.mark.parametrize('C', [1, 2, 3, 4, 5, 6, 8, 12, 16, 17, 31, 32, 33, 48, 64, 65, 91, 100, 128, 200, 256, 384, 1000, 4096])
 def test_class_counts_exercise_every_scan_geometry(C):
     """The score scan picks its read width (1 / 2 / 4 floats), lanes per row and tile height from C;
