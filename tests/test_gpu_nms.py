@@ -315,3 +315,23 @@ def test_unaligned_score_and_box_views():
                               ws.numel(), _lib.stream_ptr())
     assert rc == 0, lib.odbox_last_error()
     check((ob, os_, ol, ok, oc), c_oracle.decode_nms(anchors, regress, scores, (160, 160), threads=4))
+
+
+def test_pipeline_of_batches_in_flight_equals_single_calls():
+    """bndbox.DecodeNmsPipeline: batches alternate over two streams with their own workspaces (the tail of one
+    runs beside the score scan of the next); every batch's detections equal a plain call's, bit for bit."""
+    rng = np.random.default_rng(21)
+    N, C, B = 5000, 20, 4
+    anchors = torch.as_tensor(O.tile_anchors(O.base_anchors(32, (1, 2, .5)), 24, 24, 8)[:N]).cuda()
+    batches = []
+    for k in range(7):
+        _, regress, scores = _case(rng, B, N, C, 300 + 150 * k)
+        batches.append((torch.as_tensor(regress).cuda(), torch.as_tensor(scores).cuda()))
+    want = [BB.decode_and_nms(anchors, r, s, (200, 200), return_keep=True) for r, s in batches]
+    for depth in (1, 2, 3):
+        pipe = BB.DecodeNmsPipeline(depth=depth)
+        pending = [pipe.submit(anchors, r, s, (200, 200), return_keep=True) for r, s in batches]
+        for p, w in zip(pending, want):
+            for x, y in zip(p.result(), w):
+                assert torch.equal(x, y)
+    check(want[3], c_oracle.decode_nms(cpu(anchors), cpu(batches[3][0]), cpu(batches[3][1]), (200, 200), threads=4))
