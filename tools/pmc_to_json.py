@@ -30,7 +30,8 @@ HEAD = {'stream': 'match_encode_kernel_rotating', 'auto': 'match_encode_kernel_r
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for sub in ('stream', 'auto', 'resident', 'rest'):
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
-        for f in glob.glob(os.path.join(root, sub, counter, '*', '*counter_collection.csv')):
+        # newest run only: gpurun merges results into gpurun_out/ and never deletes an older run's files
+        for f in sorted(glob.glob(os.path.join(root, sub, counter, '*', '*counter_collection.csv')), key=os.path.getmtime)[-1:]:
             for r in csv.DictReader(open(f)):
                 name = r['Kernel_Name']
                 if sub == 'rest':
