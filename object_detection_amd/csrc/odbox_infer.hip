@@ -445,8 +445,6 @@ __device__ __forceinline__ void wave_sort_to_lds(const uint64_t *src, uint32_t n
     }
 }
 
-constexpr int SORT_THREADS = 1024;
-constexpr uint32_t SORT_LDS_CAP = 16384;   // keys cand_sort_kernel sorts in LDS (128 KiB); more: in global memory
 // The three kernels behind the scan (partition, NMS, finalize) keep their LDS under TAIL_LDS_RESERVE so that
 // they fit on a CU beside the resident scan waves of another stream's batch (the scan leaves that much free).
 constexpr size_t TAIL_LDS_RESERVE = 22 * 1024;
@@ -471,17 +469,42 @@ __host__ __device__ inline size_t part_sort_offset(int C)      // byte offset of
     return ((size_t)(C + PART_THREADS + 1) * sizeof(int) + 15) & ~(size_t)15;
 }
 
+//
+// Pre-NMS top-k (an extension, SURVEY.md 8d: the reference has no such bound; pre_nms_topk = 0 turns it off):
+// keep the pre_nms_topk highest scores of the image, ties to the lower anchor, BEFORE the class partition.
+// An image whose list is not longer than the bound -- BASELINE configs[4]: 4 500 candidates against 5 000 --
+// pays one compare for it.  A longer list is first sorted by (score desc, anchor asc), in the block's LDS
+// sort buffer up to TAIL_SORT_CAP keys and in global memory beyond, and cut to the bound; the survivors
+// then go through the partition below like any other list.
 __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
-    const int *__restrict__ cand_count, const uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out,
-    uint32_t cand_stride, int C, int *__restrict__ seg_start, int *__restrict__ coop_count, int *__restrict__ coop_list)
+    const int *__restrict__ cand_count, uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out,
+    uint32_t cand_stride, int C, uint32_t pre_nms_topk, int *__restrict__ seg_start, int *__restrict__ coop_count,
+    int *__restrict__ coop_list)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_part[];
     int *s_hist = reinterpret_cast<int *>(s_part);       // [C] counts -> cursors
     int *s_scan = s_hist + C;                            // [PART_THREADS] scan scratch, [PART_THREADS] = flag
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    const uint32_t M = min((uint32_t)cand_count[b * CNT_STRIDE], cand_stride);
-    const uint64_t *in = keys_in + (size_t)b * cand_stride;
+    uint32_t M = min((uint32_t)cand_count[b * CNT_STRIDE], cand_stride);
+    uint64_t *in = keys_in + (size_t)b * cand_stride;
     uint64_t *out = keys_out + (size_t)b * cand_stride;
+    if (pre_nms_topk != 0u && M > pre_nms_topk) {        // block-uniform
+        // (the LDS sort buffer exists when the list can hold an oversized class segment, see the launch)
+        uint64_t *s_sel = reinterpret_cast<uint64_t *>(s_part + part_sort_offset(C));
+        if (M <= TAIL_SORT_CAP && cand_stride > NMS_SEG_LDS) {
+            for (uint32_t i = tid; i < M; i += PART_THREADS) s_sel[i] = cand_to_topk(in[i]);
+            __syncthreads();
+            sort_u64<true>(s_sel, M, tid, PART_THREADS);
+            for (uint32_t i = tid; i < pre_nms_topk; i += PART_THREADS) in[i] = topk_to_cand(s_sel[i]);
+        } else {
+            for (uint32_t i = tid; i < M; i += PART_THREADS) in[i] = cand_to_topk(in[i]);
+            __syncthreads();
+            sort_u64<true>(in, M, tid, PART_THREADS);
+            for (uint32_t i = tid; i < pre_nms_topk; i += PART_THREADS) in[i] = topk_to_cand(in[i]);
+        }
+        M = pre_nms_topk;
+        __syncthreads();                                 // the cut list is what every thread reads below
+    }
     for (int c = tid; c < C; c += PART_THREADS) s_hist[c] = 0;
     if (tid == 0) s_scan[PART_THREADS] = 0;
     __syncthreads();
@@ -571,55 +594,6 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
     }
 }
 
-// kernel 2b (only when a pre-NMS top-k is requested, instead of kernel 2): block sort of a whole
-// image's candidate list: keep the best pre_nms_topk keys by (score desc, anchor asc), sort
-// them (class asc, score desc, anchor asc), write the segment starts.  (mode is always 0 now;
-// mode 1 = "only flagged images" is kept for experiments.)
-__global__ __launch_bounds__(SORT_THREADS) void cand_sort_kernel(
-    int *__restrict__ cand_count, uint64_t *__restrict__ cand_keys, uint32_t cand_stride, int C,
-    int pre_nms_topk, int mode, int *__restrict__ seg_start, int *__restrict__ big_flag)
-{
-    extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
-    const uint32_t b = blockIdx.x;
-    if (mode == 1 && big_flag[b] == 0) return;
-    uint64_t *gk = cand_keys + (size_t)b * cand_stride;
-    const uint32_t M0 = min((uint32_t)cand_count[b * CNT_STRIDE], cand_stride);
-    const bool topk = mode == 0 && pre_nms_topk > 0 && M0 > (uint32_t)pre_nms_topk;
-    // one instantiation per address space: LDS (ds_*) or global memory, never flat
-    auto run = [&](auto k, bool staged) {
-        uint32_t M = M0;
-        if (staged || topk) {
-            for (uint32_t i = threadIdx.x; i < M; i += SORT_THREADS) k[i] = topk ? cand_to_topk(gk[i]) : gk[i];
-            __syncthreads();
-        }
-        if (topk) {
-            sort_u64<true>(k, M, threadIdx.x, SORT_THREADS);
-            M = (uint32_t)pre_nms_topk;
-            for (uint32_t i = threadIdx.x; i < M; i += SORT_THREADS) k[i] = topk_to_cand(k[i]);
-            __syncthreads();
-        }
-        sort_u64<true>(k, M, threadIdx.x, SORT_THREADS);
-        if (staged)
-            for (uint32_t i = threadIdx.x; i < M; i += SORT_THREADS) gk[i] = k[i];
-        if (mode == 0) {
-            int *seg = seg_start + (size_t)b * (C + 1);
-            for (uint32_t i = threadIdx.x; i <= M; i += SORT_THREADS) {
-                const int c_hi = i < M ? (int)key_class(k[i]) : C;
-                const int c_lo = i > 0 ? (int)key_class(k[i - 1]) + 1 : 0;
-                for (int c = c_lo; c <= min(c_hi, C); ++c) seg[c] = (int)i;
-            }
-            if (threadIdx.x == 0) {
-                cand_count[b * CNT_STRIDE] = (int)M;
-                big_flag[b] = 1;         // every segment is already in visiting order
-            }
-        }
-    };
-    if (M0 <= SORT_LDS_CAP)
-        run(s_keys, true);
-    else
-        run(gk, false);
-}
-
 // decoded (+ clipped) box of anchor `idx` of image b: bndbox.py:88-99, :105-115
 __device__ __forceinline__ float4 candidate_box(const float4 *__restrict__ anchors,
                                                 const float4 *__restrict__ rb, size_t b, int N,
@@ -693,7 +667,7 @@ __device__ __forceinline__ float bcast_lane(float v, int j)
 
 // kernel 3: greedy NMS, one wave per (image, class) segment.  The wave first puts its segment
 // in visiting order (score desc, anchor asc): <= 64 keys in registers, <= NMS_SEG_LDS keys in
-// its own LDS, longer segments were sorted by cand_sort_kernel.  Candidates are taken 64 at a
+// its own LDS, longer segments were sorted by the partition kernel.  Candidates are taken 64 at a
 // time (one per lane): tested against the kept list, then resolved inside the chunk with
 // ballots (the lowest live lane is kept and suppresses the lanes above it).  The first 128
 // kept boxes live in REGISTERS, kept box k in lane k & 63 of register set k >> 6, and are
@@ -708,7 +682,7 @@ constexpr int NMS_REG_KEPT = 128;
 __device__ __forceinline__ void nms_wave_segment(
     unsigned char *s_raw, uint32_t block, const float4 *__restrict__ anchors, const float4 *__restrict__ rb, int N,
     int C, int do_clip, float hi_x, float hi_y, NmsThr thr, int max_ret, const uint64_t *__restrict__ cand_keys,
-    uint32_t cand_stride, const int *__restrict__ seg_start, const int *__restrict__ big_flag,
+    uint32_t cand_stride, const int *__restrict__ seg_start,
     int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys, uint32_t fin_stride,
     uint32_t total_segments, int waves_per_block, uint32_t per_wave_bytes, uint32_t sort_cap, bool coop_on, bool kept_alias,
     uint32_t dbg)
@@ -738,9 +712,8 @@ __device__ __forceinline__ void nms_wave_segment(
     float *s_area = reinterpret_cast<float *>(s_box + NMS_REG_KEPT + extra) - NMS_REG_KEPT;
 
     const uint64_t *keys = cand_keys + (size_t)b * cand_stride + start;
-    // in visiting order already: every segment of an image that went through cand_sort_kernel (the flag), and every
-    // segment longer than a block sorts itself (sorted by the partition kernel)
-    const bool presorted = big_flag[b] != 0 || m > NMS_SEG_LDS;
+    // in visiting order already: every segment longer than a wave sorts itself (sorted by the partition kernel)
+    const bool presorted = m > NMS_SEG_LDS;
     if (coop_on && !presorted && m > (uint32_t)NMS_COOP_MIN) return;       // a cooperative block's segment
     uint64_t reg_key = ~0ull;
     const uint64_t *sorted = keys;
@@ -1072,7 +1045,7 @@ __global__ __launch_bounds__(256) void zero_header_kernel(uint4 *__restrict__ p,
 __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
     const float4 *__restrict__ anchors, const float4 *__restrict__ rb, int N, int C, int do_clip,
     float hi_x, float hi_y, NmsThr thr, int max_ret, const uint64_t *__restrict__ cand_keys,
-    uint32_t cand_stride, const int *__restrict__ seg_start, const int *__restrict__ big_flag,
+    uint32_t cand_stride, const int *__restrict__ seg_start,
     const int *__restrict__ coop_count, const int *__restrict__ coop_list, uint32_t coop_blocks,
     int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys, uint32_t fin_stride,
     uint32_t total_segments, int waves_per_block, uint32_t per_wave_bytes, uint32_t sort_cap, uint32_t kept_alias,
@@ -1087,7 +1060,7 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
                        cand_stride, seg_start, coop_count, coop_list, total_segments, fin_count, fin_keys, fin_stride);
     else
         nms_wave_segment(s_raw, blockIdx.x - coop_blocks, anchors, rb, N, C, do_clip, hi_x, hi_y, thr, max_ret,
-                         cand_keys, cand_stride, seg_start, big_flag, fin_count, fin_keys, fin_stride, total_segments,
+                         cand_keys, cand_stride, seg_start, fin_count, fin_keys, fin_stride, total_segments,
                          waves_per_block, per_wave_bytes, sort_cap, coop_blocks != 0, kept_alias != 0, dbg);
 }
 
@@ -1218,8 +1191,8 @@ bool nms_layout(int B, int N, int C, int max_ret, NmsLayout &L)
     uint64_t fin = (uint64_t)C * (uint64_t)max_ret;
     if (fin > (uint64_t)N) fin = (uint64_t)N;
     L.fin_stride = (uint32_t)fin;
-    L.off_counts = 0;                                              // cand_count, fin_count (one 256-byte line per image), big_flag[B]; then the tile tickets
-    L.off_tickets = ((size_t)2 * B * CNT_STRIDE + align_up((size_t)B, 64) + CNT_STRIDE) * sizeof(int);   // ... big_flag[B], coop_count
+    L.off_counts = 0;                                              // cand_count, fin_count (one 256-byte line per image), B spare ints; then the tile tickets
+    L.off_tickets = ((size_t)2 * B * CNT_STRIDE + align_up((size_t)B, 64) + CNT_STRIDE) * sizeof(int);   // ... spare[B], coop_count
     L.off_seg = L.off_tickets + (size_t)SCAN_QUEUES * SCAN_TICKET_STRIDE * sizeof(int);
     L.off_coop = L.off_seg + align_up((size_t)B * (C + 1) * sizeof(int), 256);                      // coop_list[B*C]
     L.off_keys_a = L.off_coop + align_up((size_t)B * C * sizeof(int), 256);
@@ -1431,8 +1404,7 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
     unsigned char *ws = (unsigned char *)workspace;
     int *cand_count = (int *)(ws + L.off_counts);
     int *fin_count = cand_count + (size_t)B * CNT_STRIDE;
-    int *big_flag = cand_count + (size_t)2 * B * CNT_STRIDE;
-    int *coop_count = big_flag + align_up((size_t)B, 64);
+    int *coop_count = cand_count + (size_t)2 * B * CNT_STRIDE + align_up((size_t)B, 64);
     int *coop_list = (int *)(ws + L.off_coop);
     int *tile_ticket = (int *)(ws + L.off_tickets);
     int *seg_start = (int *)(ws + L.off_seg);
@@ -1456,25 +1428,15 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
                       : launch_scan<1>(scores, B, N, C, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, st);
     if (rc) return rc;
 
-    // kernel 2: group by class (counting sort), or the full block sort when a top-k is requested
-    const size_t sort_lds = (size_t)(L.cand_stride < SORT_LDS_CAP ? L.cand_stride : SORT_LDS_CAP) * 8;
-    if (int r2 = allow_lds(cand_sort_kernel, sort_lds)) return r2;
-    const uint64_t *nms_keys;
-    if (pre_nms_topk > 0) {
-        hipLaunchKernelGGL(cand_sort_kernel, dim3(B), dim3(SORT_THREADS), sort_lds, st, cand_count, keys_a,
-                           L.cand_stride, C, pre_nms_topk, 0, seg_start, big_flag);
-        if (int r2 = launch_status("cand_sort")) return r2;
-        nms_keys = keys_a;
-    } else {
-        // hist + scan scratch, then room to sort one oversized class segment (only lists that can hold one need it)
-        const size_t part_sort = L.cand_stride > NMS_SEG_LDS ? (size_t)(L.cand_stride < TAIL_SORT_CAP ? L.cand_stride : TAIL_SORT_CAP) * 8 : 0;
-        const size_t part_lds = part_sort_offset(C) + part_sort;
-        if (int r2 = allow_lds(cand_partition_kernel, part_lds)) return r2;
-        hipLaunchKernelGGL(cand_partition_kernel, dim3(B), dim3(PART_THREADS), part_lds, st, cand_count, keys_a, keys_b,
-                           L.cand_stride, C, seg_start, coop_count, coop_list);
-        if (int r2 = launch_status("cand_partition")) return r2;
-        nms_keys = keys_b;
-    }
+    // kernel 2: the pre-NMS top-k where it binds, then group by class (counting sort)
+    // hist + scan scratch, then room to sort one oversized class segment (only lists that can hold one need it)
+    const size_t part_sort = L.cand_stride > NMS_SEG_LDS ? (size_t)(L.cand_stride < TAIL_SORT_CAP ? L.cand_stride : TAIL_SORT_CAP) * 8 : 0;
+    const size_t part_lds = part_sort_offset(C) + part_sort;
+    if (int r2 = allow_lds(cand_partition_kernel, part_lds)) return r2;
+    hipLaunchKernelGGL(cand_partition_kernel, dim3(B), dim3(PART_THREADS), part_lds, st, cand_count, keys_a, keys_b,
+                       L.cand_stride, C, (uint32_t)pre_nms_topk, seg_start, coop_count, coop_list);
+    if (int r2 = launch_status("cand_partition")) return r2;
+    const uint64_t *nms_keys = keys_b;
 
     // kernel 3: per-(image, class) greedy NMS
     const size_t nms_extra = max_ret > NMS_REG_KEPT ? (size_t)(max_ret - NMS_REG_KEPT) : 0;
@@ -1489,8 +1451,8 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
     }
     const uint64_t segs = (uint64_t)B * C;
     const NmsThr nms_thr = {iou_thr, iou_thr * (1.0f - 0x1p-20f), iou_thr * (1.0f + 0x1p-20f)};
-    // cooperative blocks need the full block; their list is only built by the partition kernel
-    const uint32_t coop_blocks = (waves == NMS_WAVES && pre_nms_topk == 0) ? (uint32_t)(segs < ODBOX_COOP_BLOCKS ? segs : ODBOX_COOP_BLOCKS) : 0u;
+    // cooperative blocks need the full block
+    const uint32_t coop_blocks = waves == NMS_WAVES ? (uint32_t)(segs < ODBOX_COOP_BLOCKS ? segs : ODBOX_COOP_BLOCKS) : 0u;
     uint32_t kept_alias = 0;
 #ifndef ODBOX_TUNING_HOOKS                                         // (the experiment switches can route a sorted segment to the general path)
     if (coop_blocks) {                                             // sort buffer and kept keys are never live together: share
@@ -1504,7 +1466,7 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
     if (int r3 = allow_lds(nms_kernel, nms_lds)) return r3;
     hipLaunchKernelGGL(nms_kernel, dim3((uint32_t)nms_grid), dim3(waves * WAVE), nms_lds, st, (const float4 *)anchors,
                        (const float4 *)regress_or_boxes, N, C, do_clip, hi_x, hi_y, nms_thr, max_ret, nms_keys,
-                       L.cand_stride, seg_start, big_flag, (const int *)coop_count, (const int *)coop_list, coop_blocks,
+                       L.cand_stride, seg_start, (const int *)coop_count, (const int *)coop_list, coop_blocks,
                        fin_count, fin_keys, L.fin_stride, (uint32_t)segs, waves, (uint32_t)per_wave, sort_cap, kept_alias,
                        (uint32_t)(tuning_env("ODBOX_NMS_DBG") ? atoi(tuning_env("ODBOX_NMS_DBG")) : 0));
     if (int r3 = launch_status("nms")) return r3;

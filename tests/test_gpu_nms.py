@@ -186,6 +186,28 @@ def test_pre_nms_topk_extension():
     check(a, c_oracle.decode_nms(anchors, regress, scores, (160, 160)))
 
 
+def test_pre_nms_topk_binds_on_some_images_only():
+    """The selection kernel behind the scan: image 0 has 3 600 candidates (sorted in global memory, cut to 3 000),
+    image 1 about 1 500 (sorted in LDS, cut to 1 000 in the second call), image 2 about 200 (never touched);
+    scores quantised to 1/64, so the cut falls inside a run of equal scores and the lower anchors must stay."""
+    rng = np.random.default_rng(31)
+    N, C = 6000, 12
+    anchors, regress, scores = _case(rng, 3, N, C, 1, quant=64)
+    scores[:] = rng.uniform(0, 0.25, scores.shape).astype(F)
+    for b, hot in enumerate((3600, 1500, 200)):
+        idx = rng.permutation(N)[:hot]
+        scores[b, idx, rng.integers(0, C, hot)] = (np.floor((0.3 + 0.7 * rng.uniform(size=hot)) * 64) / 64 + 1 / 128).astype(F)
+    best = scores.max(-1)
+    assert [(best[b] > 0.3).sum() for b in range(3)] == [3600, 1500, 200]
+    for topk in (3000, 1000):
+        masked = scores.copy()
+        for b in range(3):
+            order = sorted(range(N), key=lambda i: (-float(best[b, i]), i))
+            masked[b, order[topk:]] = 0
+        got = BB.decode_and_nms(anchors, regress, scores, (160, 160), pre_nms_topk=topk, return_keep=True)
+        check(got, c_oracle.decode_nms(anchors, regress, masked, (160, 160), threads=4))
+
+
 def test_idempotent_and_workspace_reuse():
     rng = np.random.default_rng(8)
     anchors, regress, scores = _case(rng, 2, 1500, 10, 600)

@@ -59,9 +59,14 @@ def main():
             B = 64
             reg, sc = workloads.nms_inputs(N, C=c['C'], batch=B, p3p4_anchors=9 * (64 * 64 + 32 * 32))
             reg, sc = torch.as_tensor(reg).to(dev), torch.as_tensor(sc).to(dev)
-            t = event_time(lambda: BB.decode_and_nms(anchors, reg, sc, (c['S'], c['S'])), args.iters)
+            # BASELINE names a pre-NMS top-k of 5000 (it never binds on these inputs); measured in turns with the unbounded call
+            t0 = event_time(lambda: BB.decode_and_nms(anchors, reg, sc, (c['S'], c['S'])), args.iters)
+            t = event_time(lambda: BB.decode_and_nms(anchors, reg, sc, (c['S'], c['S']), pre_nms_topk=5000), args.iters)
+            t0 = min(t0, event_time(lambda: BB.decode_and_nms(anchors, reg, sc, (c['S'], c['S'])), args.iters))
+            t = min(t, event_time(lambda: BB.decode_and_nms(anchors, reg, sc, (c['S'], c['S']), pre_nms_topk=5000), args.iters))
             byts = B * workloads.nms_bytes_per_image(N, c['C'])
-            rows.append(dict(cfg=cfg, B=B, N=N, us=t * 1e6, img_s=B / t, GBs=byts / t / 1e9, frac_hbm=byts / t / 1e9 / HBM))
+            rows.append(dict(cfg=cfg, B=B, N=N, us=t * 1e6, img_s=B / t, GBs=byts / t / 1e9, frac_hbm=byts / t / 1e9 / HBM,
+                             pre_nms_topk=5000, us_without_topk=t0 * 1e6))
             continue
         B = {1: 8, 2: 64, 3: 32, 4: 128}[cfg]
         gt, lab = workloads.match_inputs(cfg, batch=B)

@@ -108,6 +108,27 @@ __global__ __launch_bounds__(BS) void fill_big_block(v4f *p, uint32_t per_block,
         }
 }
 
+
+// K: persistent blocks in lockstep over small block-contiguous chunks: block k writes chunks k, k + grid, ...
+// (chunk_vec vectors each; `burn` clock64 ticks of VALU-free waiting per chunk stand in for a match)
+template <bool NT>
+__global__ __launch_bounds__(256) void fill_chunks_persistent(v4f *p, uint32_t chunk_vec, uint32_t chunks, size_t nvec, uint32_t burn)
+{
+    const v4f z = {0, 0, 0, 0};
+    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        if (burn) {
+            const long long t0 = clock64();
+            while (clock64() - t0 < (long long)burn) __builtin_amdgcn_s_sleep(1);
+        }
+        const size_t base = (size_t)c * chunk_vec;
+        for (uint32_t v = threadIdx.x; v < chunk_vec; v += 256)
+            if (base + v < nvec) {
+                if (NT) __builtin_nontemporal_store(z, p + base + v);
+                else p[base + v] = z;
+            }
+    }
+}
+
 template <typename F>
 static float timed(F launch_, hipStream_t st)
 {
@@ -142,6 +163,16 @@ int main(int argc, char **argv)
     const uint32_t per_block = 256 * 81 / 4;                // one 256-anchor tile: 5184 vectors = 83 KB
     const uint32_t blocks = (uint32_t)((nvec + per_block - 1) / per_block);
     printf("bytes %zu, tile blocks %u, %d buffer(s) in rotation\n", bytes, blocks, sets);
+    for (uint32_t g : {256u, 512u, 1024u})
+        for (uint32_t cv : {256u, 512u, 1024u, 1296u, 2592u}) {          // 4 KB, 8 KB, 16 KB, one / two 64-anchor tiles
+            const uint32_t chunks = (uint32_t)((nvec + cv - 1) / cv);
+            printf("K persistent %4u blocks x %5u B chunks: %.2f us  nt %.2f us  nt+burn50 %.2f us  nt+burn100 %.2f us\n", g, cv * 16,
+                   timed([&] { fill_chunks_persistent<false><<<g, 256, 0, st>>>(p, cv, chunks, nvec, 0); }, st),
+                   timed([&] { fill_chunks_persistent<true><<<g, 256, 0, st>>>(p, cv, chunks, nvec, 0); }, st),
+                   timed([&] { fill_chunks_persistent<true><<<g, 256, 0, st>>>(p, cv, chunks, nvec, 50); }, st),
+                   timed([&] { fill_chunks_persistent<true><<<g, 256, 0, st>>>(p, cv, chunks, nvec, 100); }, st));
+        }
+    if (argc > 3) return 0;
     printf("hipMemsetAsync            %.2f us\n", timed([&] { CHECK(hipMemsetAsync(p, 0, bytes, st)); }, st));
     printf("A block chunk (tile)      %.2f us\n", timed([&] { fill_block_chunk<<<blocks, 256, 0, st>>>(p, per_block, nvec); }, st));
     for (uint32_t pb : {1024u, 2048u, 10368u, 20736u}) {
