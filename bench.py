@@ -257,6 +257,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-nms', action='store_true')
     ap.add_argument('--no-loss', action='store_true')
+    ap.add_argument('--no-nms-pipeline', action='store_true',
+                    help='decode+NMS one batch at a time only (clean per-kernel durations under rocprofv3: with two '
+                         'batches in flight the tail kernels of one batch are stretched over the scan of the other)')
     ap.add_argument('--no-configs', action='store_true', help='skip the configs[0] / [2] / [3] sub-objects')
     ap.add_argument('--loss-steps', type=int, default=50)
     ap.add_argument('--selftest-child', nargs='?', const='ok', default=None, help=argparse.SUPPRESS)
@@ -452,6 +455,11 @@ def main():
             'note': 'one batch at a time on one stream: the latency of a call; partition / NMS / top-k (55 us) run '
                     'behind the 178 us score scan with the memory system idle'}
 
+        if args.no_nms_pipeline:
+            single['metric'] = 'images/sec decode+clip+per-class NMS+top-k, one batch at a time'
+            result['decode_nms'] = single
+            args.no_nms = True
+    if not args.no_nms:
         # two batches in flight (bndbox.DecodeNmsPipeline): the scan of batch k+1 runs beside the tail of batch k
         pipe = BB.DecodeNmsPipeline(depth=2)
         ksteps = max(args.nms_steps, 2) * 3
