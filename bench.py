@@ -510,6 +510,49 @@ def main():
             'pipelined_equals_single_stream': bool(same),
             'detections_per_image_mean': float((out['det'][1] > 0).sum().item()) / (world * B5),
         }
+        # the same batch handed over as bfloat16 model outputs (odbox_decode_nms_mixed): half the score bytes, the
+        # detections of the widened tensors; reported beside the fp32 figures, never in their place
+        sc16, reg16 = sc5.to(torch.bfloat16), reg5.to(torch.bfloat16)
+        bytes16 = B5 * (N5 * (16 + 8 + 2 * C5) + 24 * 100)
+
+        def nms16_step(i):
+            b, s, l = BB.decode_and_nms(anchors5, reg16, sc16, (S5, S5), pre_nms_topk=5000)
+            out['det16'] = oddist.gather_detections(b, s, l, batch=None)
+
+        def pipelined16(k):
+            prev = None
+            for _ in range(k):
+                cur = pipe.submit(anchors5, reg16, sc16, (S5, S5), pre_nms_topk=5000, inputs_ready=True)
+                if prev is not None:
+                    out['det16'] = oddist.gather_detections(*prev.result(), batch=None)
+                prev = cur
+            out['det16'] = oddist.gather_detections(*prev.result(), batch=None)
+
+        wall16, ev16 = timed(nms16_step, args.nms_steps, 3, world)
+        med16, _ = per_step_median(nms16_step, per_group=4)
+        pipelined16(4)
+        torch.cuda.synchronize()
+        barrier(world)
+        t0 = time.perf_counter()
+        pipelined16(ksteps)
+        torch.cuda.synchronize()
+        barrier(world)
+        wall16p = max_over_ranks(time.perf_counter() - t0, world)
+        want16 = BB.decode_and_nms(anchors5, reg16.float(), sc16.float(), (S5, S5), pre_nms_topk=5000)
+        got16 = BB.decode_and_nms(anchors5, reg16, sc16, (S5, S5), pre_nms_topk=5000)
+        result['decode_nms']['bf16_model_outputs'] = {
+            'note': 'regressors and class scores as bfloat16 (what a PyTorch-ROCm model hands over under autocast), '
+                    'widened exactly where they are read; not the reference precision, so not part of `value`',
+            'single_stream': {'value': round(world * B5 * args.nms_steps / wall16, 1), 'unit': 'images/s',
+                              'ms_per_step': round(wall16 / args.nms_steps * 1e3, 4),
+                              'roofline': hbm_roofline('whole decode+NMS pipeline, 16-bit score scan', bytes16,
+                                                       ev16 / args.nms_steps, med16, None)},
+            'pipelined': {'value': round(world * B5 * ksteps / wall16p, 1), 'unit': 'images/s',
+                          'ms_per_step': round(wall16p / ksteps * 1e3, 4),
+                          'frac': round(bytes16 / (wall16p / ksteps) / 1e9 / HBM_PEAK_GBS, 4)},
+            'equals_fp32_path_on_widened_inputs': bool(all(torch.equal(a, b) for a, b in zip(got16, want16))),
+        }
+        del sc16, reg16
         if cb5 is not None:
             result['decode_nms']['cpu_baseline'] = {
                 'value': round(cb5['multi'][0], 1), 'unit': 'images/s', 'cores': cb5['multi'][1], 'kind': 'port',

@@ -227,6 +227,26 @@ int odbox_decode_nms(const float *anchors /*[N,4] or NULL*/, const float *regres
                      int32_t *out_labels /*[B,max_ret]*/, int32_t *out_keep_anchor /*[B,max_ret]*/,
                      int32_t *out_count /*[B]*/, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Element types of model outputs handed to odbox_decode_nms_mixed. */
+#define ODBOX_DTYPE_F32 0
+#define ODBOX_DTYPE_F16 1   /* IEEE binary16 */
+#define ODBOX_DTYPE_BF16 2  /* bfloat16 */
+
+/* odbox_decode_nms for a model that emits 16-bit outputs (PyTorch autocast on this GPU: bfloat16; the
+ * reference's own mixed-precision mode, detection.py:296-300: float16).  Same path, same outputs (fp32 boxes and
+ * scores, int32 labels), same workspace: regress_or_boxes [B,N,4] of box_dtype and scores [B,N,C] of score_dtype
+ * are widened exactly to fp32 where they are read, so the result is what odbox_decode_nms gives for the widened
+ * tensors, bit for bit, at half the bytes of the score stream that bounds the call.  No counterpart in the
+ * reference (encoder.py:200-214 runs the tail in fp32).  16-bit scores are read two classes per dword: C must
+ * be even (ODBOX_EINVAL otherwise).  16-bit boxes must be 8-byte aligned. */
+int odbox_decode_nms_mixed(const float *anchors /*[N,4] or NULL*/, const void *regress_or_boxes /*[B,N,4]*/,
+                           int box_dtype, const void *scores /*[B,N,C]*/, int score_dtype, int B, int N, int C,
+                           float img_h, float img_w, int do_clip,
+                           float score_thr, float iou_thr, int max_ret, int pre_nms_topk,
+                           float *out_boxes /*[B,max_ret,4]*/, float *out_scores /*[B,max_ret]*/,
+                           int32_t *out_labels /*[B,max_ret]*/, int32_t *out_keep_anchor /*[B,max_ret]*/,
+                           int32_t *out_count /*[B]*/, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- evaluation side: the step after the all-gather of detections ---- */
 
 /* evaluate.py:14-28 _COCO_result / :31-55 _COCO_gt_annot: xyxy -> (x, y, w, h) with fp32 w = x1-x0,

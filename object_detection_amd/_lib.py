@@ -50,6 +50,8 @@ SIGNATURES = {
     'odbox_decode_nms_workspace': (_sz, [_i, _i, _i, _i, _i]),
     'odbox_decode_nms': (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _f, _i, _i,
                               _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'odbox_decode_nms_mixed': (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _f, _i, _f, _f, _i, _i,
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'odbox_coco_records': (_i, [_vp, _sz, _vp, _vp, _vp, _vp]),
     'odbox_coco_iou': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     'odbox_coco_match_workspace': (_sz, [_i, _i]),

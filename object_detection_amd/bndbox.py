@@ -94,6 +94,15 @@ def bbox_overlap(bboxes, gt_bboxes) -> torch.Tensor:
     return out
 
 
+_KIND_DTYPE = {0: torch.float32, 1: torch.float16, 2: torch.bfloat16}       # ODBOX_DTYPE_* of include/odbox.h
+
+
+def _half_kind(x):
+    if isinstance(x, torch.Tensor):
+        return 1 if x.dtype == torch.float16 else 2 if x.dtype == torch.bfloat16 else 0
+    return 0
+
+
 def _workspace(lib, dev, B, N, C, max_ret, topk):
     need = lib.odbox_decode_nms_workspace(B, N, C, max_ret, topk)
     if need == 0:
@@ -106,8 +115,16 @@ def _decode_nms(anchors, regress_or_boxes, class_scores, im_size, do_clip,
                 score_threshold, iou_threshold, max_ret, pre_nms_topk, extras):
     lib = _lib.load()
     dev = _lib.require_gpu()
-    rb = _lib.as_dev(regress_or_boxes, torch.float32, dev)
-    sc = _lib.as_dev(class_scores, torch.float32, dev)
+    # 16-bit model outputs (autocast: bfloat16; the reference's mixed_float16: float16) go to the library as
+    # they are and are widened where they are read (odbox_decode_nms_mixed): the result is the fp32 path's for
+    # the widened tensors, at half the bytes of the score stream.  An odd class count has no 16-bit path
+    # (two classes per dword): widened here, like everything that is not a 16-bit torch tensor.
+    sc_dt = _half_kind(class_scores)
+    if sc_dt and int(class_scores.shape[-1]) % 2:
+        sc_dt = 0
+    rb_dt = _half_kind(regress_or_boxes)
+    rb = _lib.as_dev(regress_or_boxes, _KIND_DTYPE[rb_dt], dev)
+    sc = _lib.as_dev(class_scores, _KIND_DTYPE[sc_dt], dev)
     if sc.dim() != 3 or rb.dim() != 3 or rb.shape[2] != 4 or rb.shape[:2] != sc.shape[:2]:
         raise ValueError('need boxes/regressors [B,N,4] and class_scores [B,N,C]; got %r, %r'
                          % (tuple(rb.shape), tuple(sc.shape)))
@@ -125,11 +142,14 @@ def _decode_nms(anchors, regress_or_boxes, class_scores, im_size, do_clip,
     if B > 0:
         ws = _workspace(lib, dev, B, N, C, max_ret, int(pre_nms_topk))
         h, w = (float(im_size[0]), float(im_size[1])) if im_size is not None else (0.0, 0.0)
-        _lib.check(lib.odbox_decode_nms(
-            _lib.ptr(anchors), _lib.ptr(rb), _lib.ptr(sc), B, N, C, h, w, int(bool(do_clip)),
-            float(score_threshold), float(iou_threshold), max_ret, int(pre_nms_topk),
-            _lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(labels), _lib.ptr(keep), _lib.ptr(count),
-            _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), 'odbox_decode_nms')
+        tail = (B, N, C, h, w, int(bool(do_clip)), float(score_threshold), float(iou_threshold), max_ret,
+                int(pre_nms_topk), _lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(labels), _lib.ptr(keep), _lib.ptr(count),
+                _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+        if sc_dt or rb_dt:
+            _lib.check(lib.odbox_decode_nms_mixed(_lib.ptr(anchors), _lib.ptr(rb), rb_dt, _lib.ptr(sc), sc_dt, *tail),
+                       'odbox_decode_nms_mixed')
+        else:
+            _lib.check(lib.odbox_decode_nms(_lib.ptr(anchors), _lib.ptr(rb), _lib.ptr(sc), *tail), 'odbox_decode_nms')
     if extras:
         return boxes, scores, labels, keep, count
     return boxes, scores, labels

@@ -10,6 +10,7 @@
 #include "odbox_common.h"
 #include <map>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 
 using namespace odbox;
@@ -156,12 +157,39 @@ constexpr uint32_t SCAN_QUEUES = 64;       // ticket counters (tile queues)
 constexpr uint32_t SCAN_TICKET_STRIDE = 64;   // ints between counters: atomics on one cache line serialise
 constexpr uint32_t SCAN_MAX_ROWS = 512;    // rows per tile; also the size of the pending-key list
 
-template <int V, int LL>
+// 16-bit scores (HALF; odbox_decode_nms_mixed): the [B*N, C] matrix of binary16 / bfloat16 scores is read as a
+// [B*N, C/2] matrix of dwords, two classes per dword (C even), so tiles, DMA and LDS reads are the fp32 kernel's
+// with half the columns.  Both formats are sign-magnitude with the exponent above the mantissa: as SIGNED 16-bit
+// integers every positive value is above every negative one and positive values keep their order, so with a
+// threshold >= 0 the row maximum that matters (a row counts only if its maximum exceeds the threshold, hence is
+// positive) is a packed integer maximum of the raw bits (v_pk_max_i16: one instruction per two classes, the
+// fp32 kernel's rate per byte).  A negative threshold takes the general form: x ^ ((x >> 15) & 0x7fff) maps every
+// finite value to a two's complement integer of the same order (the map is its own inverse).  The maximum is
+// widened exactly (fp16: v_cvt_f32_f16, bf16: a shift) and from there on the kernel is the fp32 one: same keys.
+typedef short v2i16 __attribute__((ext_vector_type(2)));
+enum : uint32_t { HALF_BF16 = 1u, HALF_GENERAL = 2u };
+__device__ __forceinline__ uint32_t h16_ordered(uint32_t x)          // two halves at once, involutive
+{
+    const v2i16 sh = {15, 15};
+    const uint32_t sign = __builtin_bit_cast(uint32_t, __builtin_bit_cast(v2i16, x) >> sh);    // 0xffff where negative
+    return x ^ (sign & 0x7fff7fffu);
+}
+__device__ __forceinline__ uint32_t h16_max(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2i16, a), __builtin_bit_cast(v2i16, b)));
+}
+__device__ __forceinline__ float h16_widen(uint32_t bits16, bool bf16)
+{
+    return bf16 ? __uint_as_float(bits16 << 16) : (float)__builtin_bit_cast(_Float16, (uint16_t)bits16);
+}
+
+template <int V, int LL, bool HALF>
 __global__ __launch_bounds__(WAVE) void score_scan_kernel(
     const float *__restrict__ scores, int N, int C, ScanGeom g, float score_thr, uint32_t tiles_per_image,
     uint32_t total_tiles, int *__restrict__ tile_ticket, int *__restrict__ cand_count,
-    uint64_t *__restrict__ cand_keys, uint32_t cand_stride, uint32_t nq_arg, uint32_t dbg)
+    uint64_t *__restrict__ cand_keys, uint32_t cand_stride, uint32_t nq_arg, uint32_t half_mode, uint32_t dbg)
 {
+    // (HALF: `scores` points at 16-bit data and C counts DWORDS per row, i.e. classes / 2)
     ODBOX_NO_EXPERIMENTS(dbg);
     extern __shared__ __attribute__((aligned(16))) float s_buf[];     // 2 tile buffers, then the pending keys
     constexpr uint32_t LPR = 1u << LL;                  // lanes per row
@@ -245,40 +273,104 @@ __global__ __launch_bounds__(WAVE) void score_scan_kernel(
             const bool live = row < rows;
             // lanes past the last row read the last row (valid address) and drop the result
             const float *rowp = buf + min(row, rows - 1) * (uint32_t)C + sub * V;
-            float m0 = -INFINITY, m1 = -INFINITY;
-            int k = 0;
+            float m;
+            if constexpr (!HALF) {
+                float m0 = -INFINITY, m1 = -INFINITY;
+                int k = 0;
 #pragma unroll 4
-            for (; k + 2 <= g.kfull; k += 2) {
-                float v0[V], v1[V];
-                VecLoad<V>::load(rowp + (uint32_t)k * stride_k, v0);
-                VecLoad<V>::load(rowp + (uint32_t)(k + 1) * stride_k, v1);
+                for (; k + 2 <= g.kfull; k += 2) {
+                    float v0[V], v1[V];
+                    VecLoad<V>::load(rowp + (uint32_t)k * stride_k, v0);
+                    VecLoad<V>::load(rowp + (uint32_t)(k + 1) * stride_k, v1);
 #pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    m0 = fmaxf(m0, v0[e]);
-                    m1 = fmaxf(m1, v1[e]);
+                    for (int e = 0; e < V; ++e) {
+                        m0 = fmaxf(m0, v0[e]);
+                        m1 = fmaxf(m1, v1[e]);
+                    }
                 }
-            }
-            for (; k < g.K; ++k) {                       // odd read and the partial last read
-                const bool ok = ((uint32_t)k * LPR + sub) * V < (uint32_t)C;
-                float v0[V];
-                VecLoad<V>::load(ok ? rowp + (uint32_t)k * stride_k : rowp, v0);
+                for (; k < g.K; ++k) {                       // odd read and the partial last read
+                    const bool ok = ((uint32_t)k * LPR + sub) * V < (uint32_t)C;
+                    float v0[V];
+                    VecLoad<V>::load(ok ? rowp + (uint32_t)k * stride_k : rowp, v0);
 #pragma unroll
-                for (int e = 0; e < V; ++e) m0 = fmaxf(m0, ok ? v0[e] : -INFINITY);
+                    for (int e = 0; e < V; ++e) m0 = fmaxf(m0, ok ? v0[e] : -INFINITY);
+                }
+                m = group_max<LL>(fmaxf(m0, m1));
+            } else {
+                // packed signed-integer maxima of the raw (or order-mapped) bits; 0x8000 = the smallest int16
+                auto fold_row = [&](auto general_c) {
+                    constexpr bool GENERAL = decltype(general_c)::value;
+                    uint32_t a0 = 0x80008000u, a1 = 0x80008000u;
+                    int k = 0;
+#pragma unroll 8
+                    for (; k + 2 <= g.kfull; k += 2) {
+                        float v0[V], v1[V];
+                        VecLoad<V>::load(rowp + (uint32_t)k * stride_k, v0);
+                        VecLoad<V>::load(rowp + (uint32_t)(k + 1) * stride_k, v1);
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            const uint32_t x0 = __float_as_uint(v0[e]), x1 = __float_as_uint(v1[e]);
+                            a0 = h16_max(a0, GENERAL ? h16_ordered(x0) : x0);
+                            a1 = h16_max(a1, GENERAL ? h16_ordered(x1) : x1);
+                        }
+                    }
+                    for (; k < g.K; ++k) {
+                        const bool ok = ((uint32_t)k * LPR + sub) * V < (uint32_t)C;
+                        float v0[V];
+                        VecLoad<V>::load(ok ? rowp + (uint32_t)k * stride_k : rowp, v0);
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            const uint32_t x0 = __float_as_uint(v0[e]);
+                            a0 = h16_max(a0, ok ? (GENERAL ? h16_ordered(x0) : x0) : 0x80008000u);
+                        }
+                    }
+                    a0 = h16_max(a0, a1);
+                    a0 = h16_max(a0, a0 >> 16) & 0xffffu;                      // the larger of the two halves
+                    // general form: no finite value maps to 0x8000, so that is "this lane read nothing": -inf
+                    if (GENERAL) a0 = a0 == 0x8000u ? ((half_mode & HALF_BF16) ? 0xff80u : 0xfc00u) : (h16_ordered(a0) & 0xffffu);
+                    return a0;
+                };
+                const uint32_t top = (half_mode & HALF_GENERAL) ? fold_row(std::true_type{}) : fold_row(std::false_type{});
+                m = group_max<LL>(h16_widen(top, (half_mode & HALF_BF16) != 0u));
             }
-            const float m = group_max<LL>(fmaxf(m0, m1));
             const bool cand = live && (m > score_thr);                          // bndbox.py:205
             if (__ballot(cand) == 0ull) continue;                               // wave-uniform, common
             // rare: find tf.argmax's FIRST maximal column of the candidate rows, queue the keys
+            // (a wave-cooperative walk of each candidate row -- 64 columns per read, a ballot for the first hit --
+            // was measured in round 2: 176 -> 197 us at config 5, the ballots serialise; per-lane rows stay)
             uint32_t bcol = 0xffffffffu;
             if (cand) {
-                for (int kk = 0; kk < g.K; ++kk) {
-                    const uint32_t col = ((uint32_t)kk * LPR + sub) * V;
-                    if (col < (uint32_t)C) {
+                auto check = [&](uint32_t kk, const float (&v0)[V]) {
+                    const uint32_t col = (kk * LPR + sub) * V;
+#pragma unroll
+                    for (int e = V - 1; e >= 0; --e) {
+                        if constexpr (!HALF) {
+                            if (v0[e] == m) bcol = min(bcol, col + (uint32_t)e);
+                        } else {                         // dword col + e holds classes 2 (col + e) and 2 (col + e) + 1
+                            const uint32_t x = __float_as_uint(v0[e]);
+                            const bool bf = (half_mode & HALF_BF16) != 0u;
+                            if (h16_widen(x >> 16, bf) == m) bcol = min(bcol, 2u * (col + (uint32_t)e) + 1u);
+                            if (h16_widen(x & 0xffffu, bf) == m) bcol = min(bcol, 2u * (col + (uint32_t)e));
+                        }
+                    }
+                };
+                // SCAN_UB reads issued before the first compare: one LDS round trip per batch, not per read (at 4 500
+                // candidates per image nearly every step has a candidate row, and with 16-bit scores -- 45 dword
+                // reads per row at C = 90 -- the read-wait-compare form of this loop was what bounded the kernel)
+                constexpr int SCAN_UB = V == 4 ? 8 : 16;
+                int kk = 0;
+                for (; kk + SCAN_UB <= g.kfull; kk += SCAN_UB) {
+                    float vv[SCAN_UB][V];
+#pragma unroll
+                    for (int j = 0; j < SCAN_UB; ++j) VecLoad<V>::load(rowp + (uint32_t)(kk + j) * stride_k, vv[j]);
+#pragma unroll
+                    for (int j = 0; j < SCAN_UB; ++j) check((uint32_t)(kk + j), vv[j]);
+                }
+                for (; kk < g.K; ++kk) {
+                    if (((uint32_t)kk * LPR + sub) * V < (uint32_t)C) {
                         float v0[V];
                         VecLoad<V>::load(rowp + (uint32_t)kk * stride_k, v0);
-#pragma unroll
-                        for (int e = V - 1; e >= 0; --e)
-                            if (v0[e] == m) bcol = min(bcol, col + (uint32_t)e);
+                        check((uint32_t)kk, v0);
                     }
                 }
             }
@@ -594,13 +686,26 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
     }
 }
 
+// Where a candidate's regression offsets (or its decoded box, anchors == NULL) come from: [B,N,4] fp32, or --
+// odbox_decode_nms_mixed -- binary16 / bfloat16 model outputs, widened exactly on load (kind: ODBOX_DTYPE_*).
+struct BoxSrc {
+    const void *p;
+    int kind;
+};
+__device__ __forceinline__ float4 load_box(const BoxSrc rb, size_t row)
+{
+    if (rb.kind == ODBOX_DTYPE_F32) return reinterpret_cast<const float4 *>(rb.p)[row];
+    const uint2 d = reinterpret_cast<const uint2 *>(rb.p)[row];
+    const bool bf = rb.kind == ODBOX_DTYPE_BF16;
+    return make_float4(h16_widen(d.x & 0xffffu, bf), h16_widen(d.x >> 16, bf), h16_widen(d.y & 0xffffu, bf), h16_widen(d.y >> 16, bf));
+}
+
 // decoded (+ clipped) box of anchor `idx` of image b: bndbox.py:88-99, :105-115
-__device__ __forceinline__ float4 candidate_box(const float4 *__restrict__ anchors,
-                                                const float4 *__restrict__ rb, size_t b, int N,
+__device__ __forceinline__ float4 candidate_box(const float4 *__restrict__ anchors, const BoxSrc rb, size_t b, int N,
                                                 uint32_t idx, int do_clip, float hi_x, float hi_y)
 {
     idx = min(idx, (uint32_t)N - 1u);
-    float4 v = rb[b * (size_t)N + idx];
+    float4 v = load_box(rb, b * (size_t)N + idx);
     if (anchors) v = regress_one(anchors[idx], v);
     if (do_clip) v = clip_one(v, hi_x, hi_y);
     return v;
@@ -680,7 +785,7 @@ constexpr int NMS_WAVES = 8;
 constexpr int NMS_REG_KEPT = 128;
 
 __device__ __forceinline__ void nms_wave_segment(
-    unsigned char *s_raw, uint32_t block, const float4 *__restrict__ anchors, const float4 *__restrict__ rb, int N,
+    unsigned char *s_raw, uint32_t block, const float4 *__restrict__ anchors, const BoxSrc rb, int N,
     int C, int do_clip, float hi_x, float hi_y, NmsThr thr, int max_ret, const uint64_t *__restrict__ cand_keys,
     uint32_t cand_stride, const int *__restrict__ seg_start,
     int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys, uint32_t fin_stride,
@@ -921,7 +1026,7 @@ constexpr size_t COOP_LDS = (size_t)NMS_SEG_LDS * (8 + 8) + 2 * WAVE * (16 + 4) 
 
 __device__ __forceinline__ void nms_coop_block(
     unsigned char *s_raw, uint32_t block, uint32_t nblocks, const float4 *__restrict__ anchors,
-    const float4 *__restrict__ rb, int N, int C, int do_clip, float hi_x, float hi_y, NmsThr thr, int max_ret,
+    const BoxSrc rb, int N, int C, int do_clip, float hi_x, float hi_y, NmsThr thr, int max_ret,
     const uint64_t *__restrict__ cand_keys, uint32_t cand_stride, const int *__restrict__ seg_start,
     const int *__restrict__ coop_count, const int *__restrict__ coop_list, uint32_t total_segments,
     int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys, uint32_t fin_stride)
@@ -1043,7 +1148,7 @@ __global__ __launch_bounds__(256) void zero_header_kernel(uint4 *__restrict__ p,
 // kernel 3: the first coop_blocks blocks take the big segments cooperatively (they start first, so
 // the longest chains overlap everything else), the others run one wave per (image, class) segment.
 __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
-    const float4 *__restrict__ anchors, const float4 *__restrict__ rb, int N, int C, int do_clip,
+    const float4 *__restrict__ anchors, const BoxSrc rb, int N, int C, int do_clip,
     float hi_x, float hi_y, NmsThr thr, int max_ret, const uint64_t *__restrict__ cand_keys,
     uint32_t cand_stride, const int *__restrict__ seg_start,
     const int *__restrict__ coop_count, const int *__restrict__ coop_list, uint32_t coop_blocks,
@@ -1077,7 +1182,7 @@ constexpr int FIN_THREADS = ODBOX_FIN_THREADS;
 constexpr uint32_t FIN_CHUNK = 128;
 
 __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
-    const float4 *__restrict__ anchors, const float4 *__restrict__ rb, int N, int do_clip, float hi_x,
+    const float4 *__restrict__ anchors, const BoxSrc rb, int N, int do_clip, float hi_x,
     float hi_y, int max_ret, const int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys,
     uint32_t fin_stride, uint32_t lds_keys, float4 *__restrict__ out_boxes, float *__restrict__ out_scores,
     int32_t *__restrict__ out_labels, int32_t *__restrict__ out_keep, int32_t *__restrict__ out_count)
@@ -1307,9 +1412,9 @@ int allow_lds(K kernel, size_t bytes)
     return allow_lds_impl(reinterpret_cast<const void *>(kernel), bytes);
 }
 
-template <int V, int LL>
+template <int V, int LL, bool HALF>
 int launch_scan_inst(const float *scores, int B, int N, int C, const ScanGeom &g, float score_thr, int *tile_ticket,
-                     int *cand_count, uint64_t *cand_keys, uint32_t cand_stride, hipStream_t st)
+                     int *cand_count, uint64_t *cand_keys, uint32_t cand_stride, uint32_t half_mode, hipStream_t st)
 {
     const uint32_t R = (uint32_t)g.steps * (WAVE >> LL);
     const uint64_t tiles = ((uint64_t)N + R - 1) / R;
@@ -1339,20 +1444,21 @@ int launch_scan_inst(const float *scores, int B, int N, int C, const ScanGeom &g
     if (const char *e = tuning_env("ODBOX_SCAN_DBG")) dbg = (uint32_t)atoi(e);
     const uint64_t resident = (uint64_t)device_cu_count() * per_cu;
     const uint32_t grid = (uint32_t)(total < resident ? total : resident);
-    if (int rc = allow_lds(score_scan_kernel<V, LL>, lds_alloc)) return rc;
-    hipLaunchKernelGGL((score_scan_kernel<V, LL>), dim3(grid), dim3(WAVE), lds_alloc, st, scores, N, C, g, score_thr,
-                       (uint32_t)tiles, (uint32_t)total, tile_ticket, cand_count, cand_keys, cand_stride, nq, dbg);
+    if (int rc = allow_lds(score_scan_kernel<V, LL, HALF>, lds_alloc)) return rc;
+    hipLaunchKernelGGL((score_scan_kernel<V, LL, HALF>), dim3(grid), dim3(WAVE), lds_alloc, st, scores, N, C, g, score_thr,
+                       (uint32_t)tiles, (uint32_t)total, tile_ticket, cand_count, cand_keys, cand_stride, nq, half_mode, dbg);
     return launch_status("score_scan");
 }
 
-template <int V>
+// (C = dwords per row: classes for fp32 scores, classes / 2 for 16-bit ones)
+template <int V, bool HALF>
 int launch_scan(const float *scores, int B, int N, int C, const ScanGeom &g, float score_thr, int *tile_ticket,
-                int *cand_count, uint64_t *cand_keys, uint32_t cand_stride, hipStream_t st)
+                int *cand_count, uint64_t *cand_keys, uint32_t cand_stride, uint32_t half_mode, hipStream_t st)
 {
 #define ODBOX_SCAN_CASE(LL)                                                                                  \
     case LL:                                                                                                 \
-        return launch_scan_inst<V, LL>(scores, B, N, C, g, score_thr, tile_ticket, cand_count, cand_keys,    \
-                                       cand_stride, st)
+        return launch_scan_inst<V, LL, HALF>(scores, B, N, C, g, score_thr, tile_ticket, cand_count, cand_keys,    \
+                                             cand_stride, half_mode, st)
     switch (g.lpr_log2) {
         ODBOX_SCAN_CASE(0);
         ODBOX_SCAN_CASE(1);
@@ -1378,27 +1484,41 @@ size_t odbox_decode_nms_workspace(int B, int N, int C, int max_ret, int pre_nms_
     return L.total;
 }
 
-int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const float *scores, int B, int N,
-                     int C, float img_h, float img_w, int do_clip, float score_thr, float iou_thr, int max_ret,
-                     int pre_nms_topk, float *out_boxes, float *out_scores, int32_t *out_labels,
-                     int32_t *out_keep_anchor, int32_t *out_count, void *workspace, size_t workspace_bytes,
-                     void *stream)
+}  // extern "C"
+
+namespace {
+
+bool dtype_ok(int d) { return d == ODBOX_DTYPE_F32 || d == ODBOX_DTYPE_F16 || d == ODBOX_DTYPE_BF16; }
+
+// Body of odbox_decode_nms (fp32 model outputs: box_dtype = score_dtype = ODBOX_DTYPE_F32) and of
+// odbox_decode_nms_mixed (16-bit ones).
+int decode_nms_impl(const char *who, const float *anchors, const void *regress_or_boxes, int box_dtype, const void *scores,
+                    int score_dtype, int B, int N, int C, float img_h, float img_w, int do_clip, float score_thr,
+                    float iou_thr, int max_ret, int pre_nms_topk, float *out_boxes, float *out_scores, int32_t *out_labels,
+                    int32_t *out_keep_anchor, int32_t *out_count, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (B == 0) return 0;
     if (!regress_or_boxes || !scores || !out_boxes || !out_scores || !out_labels)
-        return fail(ODBOX_EINVAL, "odbox_decode_nms: NULL pointer");
+        return fail(ODBOX_EINVAL, "%s: NULL pointer", who);
+    if (!dtype_ok(box_dtype) || !dtype_ok(score_dtype))
+        return fail(ODBOX_EINVAL, "%s: dtypes must be ODBOX_DTYPE_F32, _F16 or _BF16", who);
     NmsLayout L;
     if (!nms_layout(B, N, C, max_ret, L))
         return fail(ODBOX_EINVAL,
-                    "odbox_decode_nms: bad shape B=%d N=%d C=%d max_ret=%d (limits: N<=%d C<=%d max_ret<=%d)", B, N, C,
+                    "%s: bad shape B=%d N=%d C=%d max_ret=%d (limits: N<=%d C<=%d max_ret<=%d)", who, B, N, C,
                     max_ret, ODBOX_MAX_ANCHORS, ODBOX_MAX_CLASSES, ODBOX_MAX_RET);
-    if (pre_nms_topk < 0) return fail(ODBOX_EINVAL, "odbox_decode_nms: pre_nms_topk < 0");
+    const bool half_scores = score_dtype != ODBOX_DTYPE_F32;
+    if (half_scores && (C & 1))
+        return fail(ODBOX_EINVAL, "%s: 16-bit scores are read two classes per dword: C=%d must be even (pad the class axis "
+                                  "with a column that never exceeds the threshold)", who, C);
+    if (pre_nms_topk < 0) return fail(ODBOX_EINVAL, "%s: pre_nms_topk < 0", who);
     if (!workspace || workspace_bytes < L.total)
-        return fail(ODBOX_ENOSPC, "odbox_decode_nms: workspace %zu bytes, need %zu", workspace_bytes, L.total);
-    if (((uintptr_t)workspace & 255u) != 0) return fail(ODBOX_EINVAL, "odbox_decode_nms: workspace must be 256-byte aligned");
-    if ((anchors && !aligned16(anchors)) || !aligned16(regress_or_boxes) || !aligned16(out_boxes) ||
+        return fail(ODBOX_ENOSPC, "%s: workspace %zu bytes, need %zu", who, workspace_bytes, L.total);
+    if (((uintptr_t)workspace & 255u) != 0) return fail(ODBOX_EINVAL, "%s: workspace must be 256-byte aligned", who);
+    const uintptr_t box_align = box_dtype == ODBOX_DTYPE_F32 ? 15u : 7u;
+    if ((anchors && !aligned16(anchors)) || ((uintptr_t)regress_or_boxes & box_align) || !aligned16(out_boxes) ||
         ((uintptr_t)scores & 3u))
-        return fail(ODBOX_EINVAL, "odbox_decode_nms: boxes must be 16-byte aligned, scores 4-byte aligned");
+        return fail(ODBOX_EINVAL, "%s: fp32 boxes must be 16-byte aligned (16-bit ones 8-byte), scores 4-byte aligned", who);
 
     hipStream_t st = (hipStream_t)stream;
     unsigned char *ws = (unsigned char *)workspace;
@@ -1412,6 +1532,7 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
     uint64_t *keys_b = (uint64_t *)(ws + L.off_keys_b);
     uint64_t *fin_keys = (uint64_t *)(ws + L.off_fin);
     const float hi_x = img_w - 1.0f, hi_y = img_h - 1.0f;
+    const BoxSrc rb = {regress_or_boxes, box_dtype};
 
     {   // counters, flags, tile tickets (L.off_seg is a multiple of 256 bytes)
         const uint32_t n16 = (uint32_t)(L.off_seg / 16);
@@ -1420,12 +1541,25 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
     }
 
     // kernel 1: score scan -> unordered candidate keys per image
-    ScanGeom g = scan_geometry(C, N);
-    g.stream = (uint64_t)B * (uint64_t)N * (uint64_t)C * sizeof(float) > (512ull << 20) ? 1u : 0u;
+    // (16-bit scores: two classes per dword, so the scan sees a [B*N, C/2] matrix of dwords)
+    const int Cd = half_scores ? C / 2 : C;
+    ScanGeom g = scan_geometry(Cd, N);
+    g.stream = (uint64_t)B * (uint64_t)N * (uint64_t)Cd * sizeof(float) > (512ull << 20) ? 1u : 0u;
     if (const char *e = tuning_env("ODBOX_SCAN_STREAM")) g.stream = atoi(e) != 0;        // tuning aid
-    int rc = g.V == 4 ? launch_scan<4>(scores, B, N, C, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, st)
-           : g.V == 2 ? launch_scan<2>(scores, B, N, C, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, st)
-                      : launch_scan<1>(scores, B, N, C, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, st);
+    const float *sp = (const float *)scores;
+    int rc;
+    if (half_scores) {
+        // the packed integer maximum of the raw bits is the row maximum whenever that maximum is positive, which is
+        // all a threshold >= 0 asks about; a negative threshold takes the order-mapped form (see the kernel)
+        const uint32_t hm = (score_dtype == ODBOX_DTYPE_BF16 ? HALF_BF16 : 0u) | (score_thr >= 0.0f ? 0u : HALF_GENERAL);
+        rc = g.V == 4 ? launch_scan<4, true>(sp, B, N, Cd, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, hm, st)
+           : g.V == 2 ? launch_scan<2, true>(sp, B, N, Cd, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, hm, st)
+                      : launch_scan<1, true>(sp, B, N, Cd, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, hm, st);
+    } else {
+        rc = g.V == 4 ? launch_scan<4, false>(sp, B, N, Cd, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, 0u, st)
+           : g.V == 2 ? launch_scan<2, false>(sp, B, N, Cd, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, 0u, st)
+                      : launch_scan<1, false>(sp, B, N, Cd, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, 0u, st);
+    }
     if (rc) return rc;
 
     // kernel 2: the pre-NMS top-k where it binds, then group by class (counting sort)
@@ -1465,7 +1599,7 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
     const uint64_t nms_grid = (segs + waves - 1) / waves + coop_blocks;
     if (int r3 = allow_lds(nms_kernel, nms_lds)) return r3;
     hipLaunchKernelGGL(nms_kernel, dim3((uint32_t)nms_grid), dim3(waves * WAVE), nms_lds, st, (const float4 *)anchors,
-                       (const float4 *)regress_or_boxes, N, C, do_clip, hi_x, hi_y, nms_thr, max_ret, nms_keys,
+                       rb, N, C, do_clip, hi_x, hi_y, nms_thr, max_ret, nms_keys,
                        L.cand_stride, seg_start, (const int *)coop_count, (const int *)coop_list, coop_blocks,
                        fin_count, fin_keys, L.fin_stride, (uint32_t)segs, waves, (uint32_t)per_wave, sort_cap, kept_alias,
                        (uint32_t)(tuning_env("ODBOX_NMS_DBG") ? atoi(tuning_env("ODBOX_NMS_DBG")) : 0));
@@ -1478,10 +1612,36 @@ int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const 
     const size_t fin_lds = fin_keys_lds * 8;
     if (int r4 = allow_lds(finalize_kernel, fin_lds)) return r4;
     hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(FIN_THREADS), fin_lds, st, (const float4 *)anchors,
-                       (const float4 *)regress_or_boxes, N, do_clip, hi_x, hi_y, max_ret, fin_count, fin_keys,
+                       rb, N, do_clip, hi_x, hi_y, max_ret, fin_count, fin_keys,
                        L.fin_stride, (uint32_t)fin_keys_lds, (float4 *)out_boxes, out_scores, out_labels, out_keep_anchor,
                        out_count);
     return launch_status("finalize");
+}
+
+}  // namespace
+
+extern "C" {
+
+int odbox_decode_nms(const float *anchors, const float *regress_or_boxes, const float *scores, int B, int N,
+                     int C, float img_h, float img_w, int do_clip, float score_thr, float iou_thr, int max_ret,
+                     int pre_nms_topk, float *out_boxes, float *out_scores, int32_t *out_labels,
+                     int32_t *out_keep_anchor, int32_t *out_count, void *workspace, size_t workspace_bytes,
+                     void *stream)
+{
+    return decode_nms_impl("odbox_decode_nms", anchors, regress_or_boxes, ODBOX_DTYPE_F32, scores, ODBOX_DTYPE_F32, B, N, C,
+                           img_h, img_w, do_clip, score_thr, iou_thr, max_ret, pre_nms_topk, out_boxes, out_scores,
+                           out_labels, out_keep_anchor, out_count, workspace, workspace_bytes, stream);
+}
+
+int odbox_decode_nms_mixed(const float *anchors, const void *regress_or_boxes, int box_dtype, const void *scores,
+                           int score_dtype, int B, int N, int C, float img_h, float img_w, int do_clip, float score_thr,
+                           float iou_thr, int max_ret, int pre_nms_topk, float *out_boxes, float *out_scores,
+                           int32_t *out_labels, int32_t *out_keep_anchor, int32_t *out_count, void *workspace,
+                           size_t workspace_bytes, void *stream)
+{
+    return decode_nms_impl("odbox_decode_nms_mixed", anchors, regress_or_boxes, box_dtype, scores, score_dtype, B, N, C,
+                           img_h, img_w, do_clip, score_thr, iou_thr, max_ret, pre_nms_topk, out_boxes, out_scores,
+                           out_labels, out_keep_anchor, out_count, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -178,6 +178,8 @@ def test_every_entry_rejects_bad_arguments_without_touching_the_gpu(lib):
         ('odbox_decode_nms', (p, p, p, 1, 4, 5000, 8.0, 8.0, 1, 0.3, 0.45, 100, 0, p, p, p, None, None, p, 1 << 30, None), -1),   # C over the key limit
         ('odbox_decode_nms', (p, p, p, 1, 4, 2, 8.0, 8.0, 1, 0.3, 0.45, 100, 0, p, p, p, None, None, p, 16, None), -3),
         ('odbox_decode_nms', (p, p, p, 1, 4, 2, 8.0, 8.0, 1, 0.3, 0.45, 100, -1, p, p, p, None, None, p, 1 << 30, None), -1),
+        ('odbox_decode_nms_mixed', (p, p, 1, p, 1, 1, 4, 3, 8.0, 8.0, 1, 0.3, 0.45, 100, 0, p, p, p, None, None, p, 1 << 30, None), -1),   # 16-bit scores, odd C
+        ('odbox_decode_nms_mixed', (p, p, 3, p, 1, 1, 4, 2, 8.0, 8.0, 1, 0.3, 0.45, 100, 0, p, p, p, None, None, p, 1 << 30, None), -1),   # unknown dtype
         ('odbox_coco_records', (None, 4, p, None, None, None), -1),
         ('odbox_coco_iou', (p, None, 1, 2, 2, p, None), -1),
         ('odbox_coco_match', (p, p, p, p, p, 1, 2, 2, 3, thr, 2, rng, 1, 100, p, p, None, None, p, p, 4, None), -3),

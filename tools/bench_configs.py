@@ -67,6 +67,14 @@ def main():
             byts = B * workloads.nms_bytes_per_image(N, c['C'])
             rows.append(dict(cfg=cfg, B=B, N=N, us=t * 1e6, img_s=B / t, GBs=byts / t / 1e9, frac_hbm=byts / t / 1e9 / HBM,
                              pre_nms_topk=5000, us_without_topk=t0 * 1e6))
+            # 16-bit model outputs (odbox_decode_nms_mixed): half the score bytes, same detections as the widened tensors
+            for name, dt in (('5_bf16_scores', torch.bfloat16), ('5_f16_scores', torch.float16)):
+                sc16, reg16 = sc.to(dt), reg.to(dt)
+                t16 = min(event_time(lambda: BB.decode_and_nms(anchors, reg16, sc16, (c['S'], c['S']), pre_nms_topk=5000), args.iters)
+                          for _ in range(2))
+                b16 = B * (N * (16 + 8 + 2 * c['C']) + 24 * 100)
+                rows.append(dict(cfg=name, B=B, N=N, us=t16 * 1e6, img_s=B / t16, GBs=b16 / t16 / 1e9, frac_hbm=b16 / t16 / 1e9 / HBM))
+                del sc16, reg16
             continue
         B = {1: 8, 2: 64, 3: 32, 4: 128}[cfg]
         gt, lab = workloads.match_inputs(cfg, batch=B)
