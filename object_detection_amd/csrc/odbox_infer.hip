@@ -537,10 +537,22 @@ __device__ __forceinline__ void wave_sort_to_lds(const uint64_t *src, uint32_t n
     }
 }
 
-// The three kernels behind the scan (partition, NMS, finalize) keep their LDS under TAIL_LDS_RESERVE so that
-// they fit on a CU beside the resident scan waves of another stream's batch (the scan leaves that much free).
-constexpr size_t TAIL_LDS_RESERVE = 22 * 1024;
-constexpr uint32_t TAIL_SORT_CAP = 2048;   // keys the partition / finalize blocks sort in LDS (16 KiB); more: in global memory
+// The three kernels behind the scan (partition, NMS, finalize) keep their LDS small enough to fit on a CU beside the
+// resident scan waves of another stream's batch.  The scan leaves TAIL_LDS_RESERVE bytes by its own count, but LDS is
+// handed out in granules coarser than 1 KB (1 280 B fits every observation): six scan waves of 23 552 B take
+// 6 x 24 320 B, and what is really left of the 160 KB is 17 920 B.  A 16 KB partition block fitted (round 2, 182 us
+// per batch with two batches in flight), an 18.8 KB one -- histogram and sort buffer side by side -- did not, and
+// every tail kernel waited for the other stream's scan to END (207 us; same-box bisection of two commits).  Hence
+// PART_SORT_CAP: histogram (2.4 KB at C = 90) + 12 KB of sort buffer = 14.7 KB.
+#ifndef ODBOX_TAIL_LDS_KB
+#define ODBOX_TAIL_LDS_KB 22
+#endif
+constexpr size_t TAIL_LDS_RESERVE = ODBOX_TAIL_LDS_KB * 1024;
+constexpr uint32_t TAIL_SORT_CAP = 2048;   // keys the finalize blocks sort in LDS (16 KiB); more: in global memory
+#ifndef ODBOX_PART_SORT_CAP
+#define ODBOX_PART_SORT_CAP 1536
+#endif
+constexpr uint32_t PART_SORT_CAP = ODBOX_PART_SORT_CAP;   // keys the partition blocks sort in LDS (12 KiB), beside their histogram
 constexpr uint32_t NMS_SEG_LDS = 512;      // keys one NMS wave sorts by itself; bigger segments: block sort
 #ifndef ODBOX_NMS_COOP_MIN
 #define ODBOX_NMS_COOP_MIN 128
@@ -549,24 +561,29 @@ constexpr int NMS_COOP_MIN = ODBOX_NMS_COOP_MIN;          // segments above this
 
 // kernel 2: counting sort of one image's candidate keys by class (LDS histogram -> scan ->
 // scatter); writes the class segment starts.  A class with more keys than an NMS block sorts on its
-// own (NMS_SEG_LDS) is put in visiting order here, segment by segment (in LDS up to TAIL_SORT_CAP keys,
+// own (NMS_SEG_LDS) is put in visiting order here, segment by segment (in LDS up to PART_SORT_CAP keys,
 // in global memory beyond): the NMS kernel takes every segment above NMS_SEG_LDS as presorted.
 #ifndef ODBOX_PART_THREADS
 #define ODBOX_PART_THREADS 512
 #endif
 constexpr int PART_THREADS = ODBOX_PART_THREADS;
 
-__host__ __device__ inline size_t part_sort_offset(int C)      // byte offset of the sort buffer behind hist + scan scratch
+__host__ __device__ constexpr size_t part_sort_offset(int C)      // byte offset of the sort buffer behind hist + scan scratch
 {
     return ((size_t)(C + PART_THREADS + 1) * sizeof(int) + 15) & ~(size_t)15;
 }
+// what six resident scan waves really leave of a CU's LDS (see TAIL_LDS_RESERVE): the tail kernels must fit into it at
+// the configuration the pipeline is measured on, or two batches in flight silently stop overlapping
+constexpr size_t TAIL_LDS_FIT = 17920;
+static_assert(part_sort_offset(90) + (size_t)PART_SORT_CAP * 8 <= TAIL_LDS_FIT, "partition block does not fit beside a scan");
+static_assert((size_t)TAIL_SORT_CAP * 8 <= TAIL_LDS_FIT, "finalize block does not fit beside a scan");
 
 //
 // Pre-NMS top-k (an extension, SURVEY.md 8d: the reference has no such bound; pre_nms_topk = 0 turns it off):
 // keep the pre_nms_topk highest scores of the image, ties to the lower anchor, BEFORE the class partition.
 // An image whose list is not longer than the bound -- BASELINE configs[4]: 4 500 candidates against 5 000 --
 // pays one compare for it.  A longer list is first sorted by (score desc, anchor asc), in the block's LDS
-// sort buffer up to TAIL_SORT_CAP keys and in global memory beyond, and cut to the bound; the survivors
+// sort buffer up to PART_SORT_CAP keys and in global memory beyond, and cut to the bound; the survivors
 // then go through the partition below like any other list.
 __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
     const int *__restrict__ cand_count, uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out,
@@ -583,7 +600,7 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
     if (pre_nms_topk != 0u && M > pre_nms_topk) {        // block-uniform
         // (the LDS sort buffer exists when the list can hold an oversized class segment, see the launch)
         uint64_t *s_sel = reinterpret_cast<uint64_t *>(s_part + part_sort_offset(C));
-        if (M <= TAIL_SORT_CAP && cand_stride > NMS_SEG_LDS) {
+        if (M <= PART_SORT_CAP && cand_stride > NMS_SEG_LDS) {
             for (uint32_t i = tid; i < M; i += PART_THREADS) s_sel[i] = cand_to_topk(in[i]);
             __syncthreads();
             sort_u64<true>(s_sel, M, tid, PART_THREADS);
@@ -674,7 +691,7 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
         const uint32_t en = min((uint32_t)s_hist[c], M);
         if (en <= st || en - st <= NMS_SEG_LDS) continue;
         const uint32_t m = en - st;
-        if (m <= TAIL_SORT_CAP) {
+        if (m <= PART_SORT_CAP) {
             for (uint32_t i = tid; i < m; i += PART_THREADS) s_keys[i] = out[st + i];
             __syncthreads();
             sort_u64<true>(s_keys, m, tid, PART_THREADS);
@@ -1564,7 +1581,7 @@ int decode_nms_impl(const char *who, const float *anchors, const void *regress_o
 
     // kernel 2: the pre-NMS top-k where it binds, then group by class (counting sort)
     // hist + scan scratch, then room to sort one oversized class segment (only lists that can hold one need it)
-    const size_t part_sort = L.cand_stride > NMS_SEG_LDS ? (size_t)(L.cand_stride < TAIL_SORT_CAP ? L.cand_stride : TAIL_SORT_CAP) * 8 : 0;
+    const size_t part_sort = L.cand_stride > NMS_SEG_LDS ? (size_t)(L.cand_stride < PART_SORT_CAP ? L.cand_stride : PART_SORT_CAP) * 8 : 0;
     const size_t part_lds = part_sort_offset(C) + part_sort;
     if (int r2 = allow_lds(cand_partition_kernel, part_lds)) return r2;
     hipLaunchKernelGGL(cand_partition_kernel, dim3(B), dim3(PART_THREADS), part_lds, st, cand_count, keys_a, keys_b,

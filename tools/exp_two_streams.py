@@ -12,7 +12,10 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from object_detection_amd import anchors as A, bndbox as BB, workloads   # noqa: E402
+from object_detection_amd import _lib, anchors as A, bndbox as BB, workloads   # noqa: E402
+
+if os.environ.get('EXP_OLDLIB'):       # a library built from an older commit (bisecting): it lacks the newest entry point
+    _lib.SIGNATURES.pop('odbox_decode_nms_mixed', None)
 
 
 def main():
@@ -24,6 +27,9 @@ def main():
     nsets = 3
     regs = [torch.as_tensor(reg_np).to(dev) for _ in range(nsets)]
     scs = [torch.as_tensor(sc_np).to(dev) for _ in range(nsets)]
+    if os.environ.get('EXP_DTYPE') in ('bf16', 'f16'):          # 16-bit model outputs (odbox_decode_nms_mixed)
+        dt = torch.bfloat16 if os.environ['EXP_DTYPE'] == 'bf16' else torch.float16
+        regs, scs = [r.to(dt) for r in regs], [x.to(dt) for x in scs]
     ref = BB.decode_and_nms(anchors, regs[0], scs[0], (S, S))
     torch.cuda.synchronize()
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
@@ -39,8 +45,17 @@ def main():
                     outs[j] = BB.decode_and_nms(anchors, regs[j], scs[j], (S, S))
         run(2 * nstreams)
         torch.cuda.synchronize()
+        if os.environ.get('EXP_OFFSET') and nstreams > 1:
+            # start the streams out of phase (stream j idles j / nstreams of a scan first): do they stay that way?
+            for j in range(1, nstreams):
+                with torch.cuda.stream(streams[j]):
+                    torch.cuda._sleep(int(float(os.environ['EXP_OFFSET']) * j / nstreams))
         best = 1e9
         for _ in range(3):
+            if os.environ.get('EXP_OFFSET') and nstreams > 1:
+                for j in range(1, nstreams):
+                    with torch.cuda.stream(streams[j]):
+                        torch.cuda._sleep(int(float(os.environ['EXP_OFFSET']) * j / nstreams))
             t0 = time.perf_counter()
             run(steps)
             torch.cuda.synchronize()
