@@ -112,7 +112,10 @@ constexpr int ZERO_LEAD = ODBOX_ZERO_LEAD;
 #define ODBOX_ME_TILE_STREAM 64                // same-box A/B, 128 -> 64: configs[2] share 358 -> 347 us, configs[1] on cold buffers 45.3 -> 43.6 us
 #endif
 constexpr int ME_TILE_STREAM = ODBOX_ME_TILE_STREAM;      // match_encode with a dense output far beyond the Infinity Cache
-constexpr int ME_GCHUNK = 512;
+#ifndef ODBOX_ME_GCHUNK
+#define ODBOX_ME_GCHUNK 512
+#endif
+constexpr int ME_GCHUNK = ODBOX_ME_GCHUNK;      // GT rows staged in LDS at a time
 #ifndef ODBOX_FAST_ROWS
 #define ODBOX_FAST_ROWS 4                  // GT rows per step of the division-free matcher loop
 #endif
@@ -1149,8 +1152,17 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
     if (blocks > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_match_encode: grid too large");
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(out_gt_best);
     const uint32_t bg = (uint32_t)B * (uint32_t)G;
+    // The streaming variant runs SIX one-wave blocks per CU, not the ten its 14.6 KB of LDS would allow: unused dynamic
+    // LDS pads every block to a sixth of the CU's 160 KB (26 880 B in 1 280-B granules).  A store stream into cold
+    // memory is fastest when few tiles are being written at once: same-box A/B on the configs[2] share (2.26 GB per
+    // launch), resident blocks per CU 10 / 8 / 6 / 5 / 4: 349 / 344 / 325-329 / 325-329 / 364 us; the configs[1] batch
+    // into cold buffers 43.4 -> 43.0 us; more blocks per CU (GT staging cut to 128 rows: 32 per CU) 45.3 and 360 us.
+#ifndef ODBOX_ME_STREAM_PAD_KB
+#define ODBOX_ME_STREAM_PAD_KB 12
+#endif
+    const size_t pad_lds = stream_out ? (size_t)ODBOX_ME_STREAM_PAD_KB * 1024 : 0;
     auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(tile), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(tile), pad_lds, (hipStream_t)stream,
                            (const float4 *)anchors, (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w,
                            neg_thr, pos_thr, out_regression, out_labels, out_match_idx, out_state, out_max_iou,
                            keys, (uint32_t)tiles, remap);
