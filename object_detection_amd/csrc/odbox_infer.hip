@@ -1349,7 +1349,11 @@ int scan_bank_conflict(int C, int V, int LL)
     return worst;
 }
 
-ScanGeom scan_geometry(int C, int N)
+// step_cap / tile_target: bytes of one wave-step at most, bytes of one tile about.  fp32 scores: 16 KB / 12 KB.
+// 16-bit scores: 8 KB / 6 KB -- their rows are half as long, and with 64 rows per step (one lane per row) a tile
+// of C = 90 was 11.5 KB again, 6 waves per CU; 32 rows per step and 6 KB tiles keep 11 waves per CU in flight
+// (same-box A/B at config 5: 99.8 -> 95.1 us; the fp32 scan does not care: 175.4 / 175.6 / 176.9 us).
+ScanGeom scan_geometry(int C, int N, size_t step_cap = 16 * 1024, size_t tile_target = 12 * 1024)
 {
     ScanGeom g{};
     g.V = (C % 4 == 0) ? 4 : (C % 2 == 0) ? 2 : 1;
@@ -1362,7 +1366,7 @@ ScanGeom scan_geometry(int C, int N)
         const int lpr = 1 << l, K = (nvec + lpr - 1) / lpr;
         const double eff = (double)nvec / ((double)K * lpr);
         const size_t step_bytes = (size_t)(WAVE >> l) * C * sizeof(float);
-        if (eff >= 0.85 && scan_bank_conflict(C, g.V, l) <= 2 && step_bytes <= 16 * 1024) pick = l;
+        if (eff >= 0.85 && scan_bank_conflict(C, g.V, l) <= 2 && step_bytes <= step_cap) pick = l;
     }
     if (pick < 0) {                    // very wide rows: keep the step small, take the best lane use
         double best = -1.0;
@@ -1370,7 +1374,7 @@ ScanGeom scan_geometry(int C, int N)
             const int lpr = 1 << l, K = (nvec + lpr - 1) / lpr;
             const double score = (double)nvec / ((double)K * lpr) / scan_bank_conflict(C, g.V, l);
             const size_t step_bytes = (size_t)(WAVE >> l) * C * sizeof(float);
-            if ((step_bytes <= 16 * 1024 || l == 6) && score > best) { best = score; pick = l; }
+            if ((step_bytes <= step_cap || l == 6) && score > best) { best = score; pick = l; }
         }
     }
     g.lpr_log2 = pick;
@@ -1380,7 +1384,7 @@ ScanGeom scan_geometry(int C, int N)
     g.kfull = nvec / lpr;
     const int rows_per_step = WAVE / lpr;
     const size_t step_bytes = (size_t)rows_per_step * C * sizeof(float);
-    int steps = (int)((12 * 1024) / step_bytes);                       // ~12 KiB per tile
+    int steps = (int)(tile_target / step_bytes);                       // ~12 KiB per tile (6 KiB for 16-bit scores)
     const int max_steps = (int)SCAN_MAX_ROWS / rows_per_step;
     g.steps = steps < 1 ? 1 : (steps > max_steps ? max_steps : steps);
     if (const char *e = tuning_env("ODBOX_SCAN_STEPS")) g.steps = atoi(e) > 0 ? atoi(e) : g.steps;
@@ -1560,7 +1564,7 @@ int decode_nms_impl(const char *who, const float *anchors, const void *regress_o
     // kernel 1: score scan -> unordered candidate keys per image
     // (16-bit scores: two classes per dword, so the scan sees a [B*N, C/2] matrix of dwords)
     const int Cd = half_scores ? C / 2 : C;
-    ScanGeom g = scan_geometry(Cd, N);
+    ScanGeom g = half_scores ? scan_geometry(Cd, N, 8 * 1024, 6 * 1024) : scan_geometry(Cd, N);
     g.stream = (uint64_t)B * (uint64_t)N * (uint64_t)Cd * sizeof(float) > (512ull << 20) ? 1u : 0u;
     if (const char *e = tuning_env("ODBOX_SCAN_STREAM")) g.stream = atoi(e) != 0;        // tuning aid
     const float *sp = (const float *)scores;
