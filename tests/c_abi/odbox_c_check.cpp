@@ -80,7 +80,7 @@ int main()
     HIP_OK(hipStreamCreate(&st));
 
     // ---- anchors: one 16 x 16 level, 9 anchors per cell, stride 8 (anchors.py:44-87) ------------
-    const int A = 9, F = 16, S = 128, N = F * F * A, B = 3, G = 12, C = 5;
+    const int A = 9, F = 16, S = 128, N = F * F * A, B = 3, G = 12, C = 6;
     std::vector<float> base(A * 4);
     for (int a = 0; a < A; ++a) {
         const float w = 16.0f + 6.0f * (float)(a % 3), h = w * (a / 3 == 0 ? 1.0f : (a / 3 == 1 ? 2.0f : 0.5f));
@@ -176,6 +176,34 @@ int main()
     printf("decode_nms:   %zu keep/label/score/count mismatches, %zu boxes beyond 1e-5 (%d, %d, %d detections)\n", bad, bad_box,
            oc_ref[0], oc_ref[1], oc_ref[2]);
     failures += bad + bad_box + (oc_ref[0] == 0);
+
+    // ---- the same call with bfloat16 scores (odbox_decode_nms_mixed): the fp32 path on the widened values --------
+    if (C % 2 == 0) {
+        std::vector<uint16_t> s16(scores.size());
+        std::vector<float> wide(scores.size());
+        for (size_t i = 0; i < scores.size(); ++i) {
+            uint32_t u;
+            memcpy(&u, &scores[i], 4);
+            u += 0x7fffu + ((u >> 16) & 1u);                 // round to nearest even
+            s16[i] = (uint16_t)(u >> 16);
+            u = (uint32_t)s16[i] << 16;
+            memcpy(&wide[i], &u, 4);
+        }
+        if (odbox_oracle_decode_nms(anchors_ref.data(), rgs.data(), wide.data(), B, N, C, (float)S, (float)S, 1, 0.3f, 0.45f, max_ret,
+                                    ob_ref.data(), os_ref.data(), ol_ref.data(), ok_ref.data(), oc_ref.data(), 1) != 0) return 2;
+        uint16_t *d_s16 = to_device(s16);
+        ODBOX_OK(odbox_decode_nms_mixed(d_anchors, d_rgs, ODBOX_DTYPE_F32, d_s16, ODBOX_DTYPE_BF16, B, N, C, (float)S, (float)S, 1, 0.3f,
+                                        0.45f, max_ret, 0, d_ob, d_os, d_ol, d_ok, d_oc, d_ws, ws_bytes, st));
+        HIP_OK(hipStreamSynchronize(st));
+        if (!from_device(ob, d_ob) || !from_device(os, d_os) || !from_device(ol, d_ol) || !from_device(ok, d_ok) || !from_device(oc, d_oc)) return 2;
+        bad = 0;
+        for (size_t i = 0; i < ok.size(); ++i) { bad += ok[i] != ok_ref[i]; bad += ol[i] != ol_ref[i]; bad += os[i] != os_ref[i]; }
+        for (int b = 0; b < B; ++b) bad += oc[b] != oc_ref[b];
+        const size_t bad_box16 = mismatches(ob.data(), ob_ref.data(), ob.size(), 1e-5f);
+        printf("decode_nms_mixed (bf16 scores): %zu keep/label/score/count mismatches, %zu boxes beyond 1e-5 (%d detections)\n", bad,
+               bad_box16, oc_ref[0]);
+        failures += bad + bad_box16 + (oc_ref[0] == 0);
+    }
 
     // ---- error convention: a bad call returns a code and a message, nothing is thrown ------------
     const int rc = odbox_decode_nms(d_anchors, d_rgs, d_scores, B, N, C, (float)S, (float)S, 1, 0.3f, 0.45f, max_ret, 0, d_ob, d_os,

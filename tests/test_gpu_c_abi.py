@@ -20,3 +20,4 @@ def test_plain_c_host_program_matches_the_oracle():
     assert r.stdout.strip().endswith('PASS')
     assert '0 index/state/one-hot mismatches, 0 offsets' in r.stdout
     assert '0 keep/label/score/count mismatches, 0 boxes' in r.stdout
+    assert 'decode_nms_mixed (bf16 scores): 0 keep/label/score/count mismatches, 0 boxes' in r.stdout
