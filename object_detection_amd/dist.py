@@ -78,11 +78,15 @@ def unpack_detections(records):
     return boxes, scores, labels
 
 
-def gather_detections(boxes, scores, labels, batch=None, group=None):
+def gather_detections(boxes, scores, labels, batch=None, group=None, always=False):
     """All ranks pass the detections of their shard ([b,R,4], [b,R], [b,R] with b =
     ceil(batch / world), short shards zero-padded here) and get the whole batch back, images in
-    rank order: one all_gather_into_tensor of [b,R,6] records."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    rank order: one all_gather_into_tensor of [b,R,6] records.  A group of one rank returns its
+    inputs untouched unless `always` is set (tests/test_zy_gpu_dist2.py runs the RCCL transport
+    itself that way on a one-GPU machine)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return boxes, scores, labels
+    if dist.get_world_size(group) == 1 and not always:
         return boxes, scores, labels
     world = dist.get_world_size(group)
     per = None if batch is None else (batch + world - 1) // world
