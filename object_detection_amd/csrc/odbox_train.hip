@@ -144,13 +144,19 @@ struct TileMatch {
 // the above (north_star's "per-GT best-anchor" reduction; the reference only has the diagnostic of
 // coco.py:399-402 and never forces a label from it).  For GT row g of image b: the anchor with the
 // largest IoU over all N anchors, ties to the LOWEST anchor (numpy / tf argmax over the anchor axis).
-// Every lane that evaluates a pair with IoU > 0 folds (ordered IoU bits, ~anchor) into the row's
-// 64-bit LDS maximum; per chunk each row's maximum goes to gbest_keys[b, g] with one global
-// atomicMax, and only if a plain load says it can still win.  Pairs the culling proves to be exactly
-// +0 post nothing: a row nobody posted for has IoU +0 everywhere (or -1: padding) and its argmax
-// is anchor 0 -- filled in by gt_best_finalize_kernel, which also recomputes the winner's IoU, so the
-// value carries the exact bits of IoU(anchor, g), sign of zero included.  Rows that cannot be
-// culled (negative-area GT rows or anchors: values below zero are possible) post every pair.
+// The block keeps one 64-bit key (ordered IoU bits, ~anchor) per staged GT row in LDS, seeded with the
+// row's key in gbest_keys[b, g] as some earlier block left it (a device-scope load; stale = low, never
+// wrong).  In the division-free loop a row costs one broadcast LDS read and one compare per lane:
+// "can my approximate quotient, at the top of its error band, reach the row's best so far".  Only a
+// wave with such a lane goes on: DPP / readlane reduction of the quotient over the wavefront, the
+// lanes within the band of the wave's maximum (one, unless anchors tie) take the exact IEEE division
+// and fold their key into the row's LDS maximum.  Per chunk each row whose key rose above its seed
+// goes to gbest_keys[b, g] with one global atomicMax.  Pairs with IoU exactly +0 (culled rows
+// included) post nothing: a row nobody posted for has IoU +0 everywhere (or -1: padding) and its
+// argmax is anchor 0 -- filled in by gt_best_finalize_kernel, which also recomputes the winner's
+// IoU, so the value carries the exact bits of IoU(anchor, g), sign of zero included.  Rows that
+// cannot be culled (negative-area GT rows or anchors: values below zero are possible) take the exact
+// loop and post every pair.
 __device__ __forceinline__ unsigned long long gbest_key(float v, uint32_t n)
 {
     return ((unsigned long long)f32_ordered(v) << 32) | (0xffffffffu - n);
@@ -164,6 +170,7 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
                                                 EarlyWork early, unsigned long long *gbest_keys = nullptr)
 {
     __shared__ unsigned long long s_gbest[GTBEST ? ME_GCHUNK : 1];
+    __shared__ unsigned long long s_gseed[GTBEST ? ME_GCHUNK : 1];
     __shared__ float4 s_gt[ME_GCHUNK];
     __shared__ float2 s_ga[ME_GCHUNK];          // (area, 1.0 if padded row else 0.0)
     __shared__ uint16_t s_list[TILE / WAVE][ME_GCHUNK];      // per wave: GT rows it must evaluate
@@ -208,7 +215,12 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
             float gmax = fmaxf(fmaxf(gb.x, gb.y), fmaxf(gb.z, gb.w));    // bndbox.py:295
             s_gt[g] = gb;
             s_ga[g] = make_float2(area, gmax < 0.0f ? 1.0f : 0.0f);
-            if (GTBEST) s_gbest[g] = 0ull;
+            if (GTBEST) {
+                // device scope: a plain load would be served by this XCD's L2, which never sees the other XCDs' atomics
+                const unsigned long long seed = __hip_atomic_load(&gbest_keys[(size_t)b * G + g0 + g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_gbest[g] = seed;
+                s_gseed[g] = seed;
+            }
         }
         // every global load issued so far has been consumed: from here to the label / box gathers at
         // the end the match is VALU and LDS work only, so memory work issued now overlaps it
@@ -252,7 +264,16 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
         // (strict >, first maximum wins).  The best row's exact IoU is computed once, after the loop.
         // Same decisions as the exact loop below, row by row, hence the same argmax and the same value
         // (tests/test_gpu_match.py::test_ties_and_near_ties_in_the_division_free_matcher).
-        if (!GTBEST && can_skip_zero && odd_rows == 0ull && nlist != 0u) {
+        auto post_chunk = [&] {
+            if (!GTBEST) return;
+            __syncthreads();                                 // every wave's maxima of this chunk are in
+            unsigned long long *dst = gbest_keys + (size_t)b * G + g0;
+            for (int g = tid; g < cnt; g += TILE) {
+                const unsigned long long k = s_gbest[g];
+                if (k > s_gseed[g]) atomicMax(&dst[g], k);
+            }
+        };
+        if (can_skip_zero && odd_rows == 0ull && nlist != 0u) {
             constexpr float BAND_HI = 1.0f + 0x1p-19f, BAND_LO = 1.0f - 0x1p-19f;
             auto exact_iou = [&](int row) {
                 const float4 bb = row >= g0 ? s_gt[row - g0] : gtb[row];
@@ -303,11 +324,47 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
                     }
                     qb = vb;
                 }
+                if (GTBEST) {
+                    // per-GT best anchor: can any lane reach the row's best so far?  The key's upper word is the
+                    // ordered IoU of a value > 0 (sign bit set on top of the float's bits), or 0 = nothing yet
+                    bool reach[R];
+                    bool any_reach = false;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const float cur = __uint_as_float(reinterpret_cast<const uint32_t *>(&s_gbest[g[r]])[1] & 0x7fffffffu);
+                        reach[r] = ia[r] > 0.0f && q[r] * BAND_HI >= cur;
+                        any_reach = any_reach || reach[r];
+                    }
+                    if (__ballot(any_reach && live) != 0ull) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            if (__ballot(reach[r] && live) == 0ull) continue;
+                            // the wave's largest quotient (all >= 0: their bits order like integers)
+                            float m = reach[r] && live ? q[r] : 0.0f;
+                            m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0xB1, 0xf, 0xf, true)));    // quad_perm [1,0,3,2]
+                            m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x4E, 0xf, 0xf, true)));    // quad_perm [2,3,0,1]
+                            m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x141, 0xf, 0xf, true)));   // row_half_mirror
+                            m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x140, 0xf, 0xf, true)));   // row_mirror
+                            const uint32_t mb = max(max((uint32_t)__builtin_amdgcn_readlane(__float_as_int(m), 0),
+                                                        (uint32_t)__builtin_amdgcn_readlane(__float_as_int(m), 16)),
+                                                    max((uint32_t)__builtin_amdgcn_readlane(__float_as_int(m), 32),
+                                                        (uint32_t)__builtin_amdgcn_readlane(__float_as_int(m), 48)));
+                            const float qmax = __uint_as_float(mb);
+                            // a lane below the band of the wave's maximum has a strictly smaller exact IoU than the lane
+                            // that holds it; the others (one lane, unless anchors tie) divide exactly and post
+                            if (reach[r] && live && q[r] * BAND_HI >= qmax) {
+                                const float v = ia[r] / ua[r];
+                                if (v > 0.0f) atomicMax(&s_gbest[g[r]], gbest_key(v, n));
+                            }
+                        }
+                    }
+                }
             };
             uint32_t k = 0;
             for (; k + FAST_ROWS <= nlist; k += FAST_ROWS) rows(k, std::integral_constant<int, FAST_ROWS>{});
             for (; k < nlist; ++k) rows(k, std::integral_constant<int, 1>{});
             best_iou = exact_iou(best);
+            post_chunk();
             continue;
         }
 #pragma unroll 2
@@ -322,17 +379,7 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
                 if (live && (v > 0.0f || forced)) atomicMax(&s_gbest[g], gbest_key(v, n));
             }
         }
-        if (GTBEST) {
-            __syncthreads();                                 // every wave's maxima of this chunk are in
-            unsigned long long *dst = gbest_keys + (size_t)b * G + g0;
-            for (int g = tid; g < cnt; g += TILE) {
-                const unsigned long long k = s_gbest[g];
-                // look before posting (a device-scope load: a plain one would be served by this XCD's L2, which
-                // never sees the other XCDs' atomics).  A stale value errs on the low side only (the keys only
-                // grow): a useless atomic at worst, never a skipped one
-                if (k != 0ull && k > __hip_atomic_load(&dst[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&dst[g], k);
-            }
-        }
+        post_chunk();
     }
     // fold the skipped rows back in: value 0 at first_zero, value -1 at first_pad; ties go to
     // the lower row like tf.argmax
