@@ -53,6 +53,19 @@ const char *odbox_last_error(void);
 #define ODBOX_POLICY_STREAM 2
 int odbox_set_output_policy(int policy);
 
+/* Which kernel odbox_match_encode would launch for dense labels of this shape under the current output
+ * policy (no counterpart in the reference; for tests, benchmarks and logs -- the results are the same
+ * bits on every plan).  TILES: one block per 256-anchor tile, stores through the caches.  TILES_STREAM:
+ * 64-anchor tiles, nontemporal stores.  SWEEP: streamed outputs with wide label rows (C + 1 >= 69), at
+ * most 64 GT rows, 16-byte aligned labels, no per-GT output and at most 768 MB of labels: the label tensor
+ * is written as one chip-wide lockstep sweep of 4 KB pieces by dedicated store waves while other waves
+ * of the same blocks match and patch (the fastest order into cold HBM).  Returns ODBOX_EINVAL on a bad
+ * shape. */
+#define ODBOX_PLAN_TILES        0
+#define ODBOX_PLAN_TILES_STREAM 1
+#define ODBOX_PLAN_SWEEP        2
+int odbox_match_encode_plan(int B, int N, int G, int C, int labels_aligned16, int want_gt_best);
+
 /* anchors.py:44-87 AnchorGenerator.tile_anchors_over_feature_map:
  * out[(i*fw + j)*A + a] = base[a] + ((j+.5)*stride, (i+.5)*stride, (j+.5)*stride, (i+.5)*stride). */
 int odbox_anchor_tile(const float *base /*[A,4]*/, int A, int fh, int fw, float stride,

@@ -99,6 +99,20 @@ def set_output_policy(policy: str) -> str:
     return {v: k for k, v in _POLICIES.items()}[prev]
 
 
+_PLANS = {0: 'tiles', 1: 'tiles_stream', 2: 'sweep'}
+
+
+def match_encode_plan(batch: int, num_anchors: int, num_gt: int, num_classes: int,
+                      labels_aligned16: bool = True, gt_best: bool = False) -> str:
+    """Which kernel `match_encode` launches for dense labels of this shape under the current output
+    policy (`odbox_match_encode_plan`): 'tiles', 'tiles_stream' or 'sweep'.  Same bits on every plan."""
+    lib = _lib.load()
+    rc = lib.odbox_match_encode_plan(batch, num_anchors, num_gt, num_classes, int(labels_aligned16), int(gt_best))
+    if rc < 0:
+        raise _lib.OdboxError(lib.odbox_last_error().decode())
+    return _PLANS[rc]
+
+
 def match_encode(anchors, image_hw, bndboxes, labels, num_classes,
                  negative_overlap=0.4, positive_overlap=0.5,
                  dense=True, compact=False, gt_best=False):

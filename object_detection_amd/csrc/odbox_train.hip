@@ -527,6 +527,201 @@ __global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE_ENC) void match_e
 }
 
 // ------------------------------------------------------------------------------------------
+// match_encode_sweep_kernel: the same outputs as match_encode_kernel<true, false>, written in the order
+// cold HBM likes best (anchors.py:116-213; same expressions, same bits).
+//
+// A store stream into COLD memory is fastest as a chip-wide lockstep sweep: every block writes one 4 KB
+// piece per step and the 512 pieces of a step are contiguous (a 2 MB window that moves through the
+// tensor): 35 us for configs[1]'s 221 MB of labels against 40-41 us for any tile-shaped pattern
+// (tools/exp/fill_shapes.hip, profiles/README.md).  The sweep keeps that rate only while its waves do
+// nothing else, so the block is specialised (tools/exp/sweep_spec.hip):
+//   SWEEP_SW store waves   piece after piece of zeros, nothing else; each publishes in LDS how many of its
+//                          pieces have reached L2 (stores complete in order: s_waitcnt vmcnt(K) leaves K
+//                          in flight, no drain).
+//   SWEEP_MW matcher waves lane = (one of four pieces, one of the <= 16 anchor rows that touch it): exact
+//                          argmax over the image's G <= 64 GT rows, states, label, offsets; compact outputs
+//                          and the regression row by the lane of the piece the row STARTS in; the non-zero
+//                          label elements (state, the one 1.0) patched by the lane of the piece each
+//                          element lies IN, once the store waves say that piece's zeros are out -- a row
+//                          that straddles two pieces is matched twice, by the two blocks that own them.
+// Taken by odbox_match_encode for streamed outputs (ODBOX_POLICY_STREAM, or AUTO beyond ODBOX_STREAM_MB)
+// with wide label rows (C + 1 >= 69: at most 16 rows per piece), G <= 64, 16-byte aligned labels of at most
+// ODBOX_SWEEP_MAX_MB and no per-GT output; everything else stays with match_encode_kernel.
+// ------------------------------------------------------------------------------------------
+#ifndef ODBOX_SWEEP_MW
+#define ODBOX_SWEEP_MW 12
+#endif
+#ifndef ODBOX_SWEEP_VMK
+#define ODBOX_SWEEP_VMK 12
+#endif
+constexpr int SWEEP_PIECE = 1024;               // floats per piece
+#ifndef ODBOX_SWEEP_SW
+#define ODBOX_SWEEP_SW 4
+#endif
+constexpr int SWEEP_SW = ODBOX_SWEEP_SW;        // store waves: 1 KB each per piece
+constexpr int SWEEP_MW = ODBOX_SWEEP_MW;        // matcher waves
+constexpr int SWEEP_RPP = 16;                   // anchor rows that can touch one piece
+constexpr int SWEEP_VMK = ODBOX_SWEEP_VMK;      // stores a store wave keeps in flight behind its progress counter
+constexpr int SWEEP_MAX_G = 64;
+#ifndef ODBOX_SWEEP_MAX_MB
+// label bytes up to which the sweep is taken.  Same-box A/B against the 64-anchor tiles on cold buffers (tools/exp_sweep.py):
+// 135 MB (configs[0]) 27.2 -> 23.4 us, 234 MB (configs[1]) 43.2 -> 39.1 us, 270 MB 49.5 -> 43.5 us, 540 MB 90-93 -> 87-88 us,
+// 1.08 GB 167-172 -> 179 us, 2.16 GB (configs[2] share) 327-332 -> 372-376 us: long launches amortise the tiles' ramp and
+// reach 6.6-6.9 TB/s, which the sweep's narrow window does not.
+#define ODBOX_SWEEP_MAX_MB 768
+#endif
+
+constexpr int SWEEP_LDS_ROWS = 3072;            // GT rows of the whole batch (B * G) a block can keep in LDS: 60 KB, two blocks per CU
+
+// GT_LDS: the batch's GT boxes and labels (B * G <= SWEEP_LDS_ROWS rows) are staged in LDS by the matcher
+// waves while the store waves already sweep; the argmax loop then reads LDS only.  Under the store stream a
+// global round trip costs microseconds, and the plain form pays G / 4 + 3 of them per batch of four pieces:
+// configs[1] into cold buffers 40.6 us without the staging (same-box A/B), against 43.5 us for the tiles.
+template <bool GT_LDS>
+__global__ __launch_bounds__(WAVE *(SWEEP_SW + SWEEP_MW)) void match_encode_sweep_kernel(
+    const float4 *__restrict__ anchors, const float4 *__restrict__ gt_boxes, const int32_t *__restrict__ gt_labels, int N,
+    int G, int C, float img_h, float img_w, float neg_thr, float pos_thr, float *__restrict__ out_reg, float *out_lab,
+    int32_t *__restrict__ out_idx, int8_t *__restrict__ out_state, float *__restrict__ out_iou, uint32_t rows,
+    uint32_t total, uint32_t pieces, uint32_t gt_rows)
+{
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    extern __shared__ float4 s_gt[];                    // GT_LDS: [gt_rows] boxes, then [gt_rows] labels
+    __shared__ volatile uint32_t s_done[SWEEP_SW];      // store wave w: the zeros of this block's pieces < s_done[w] are in L2
+    __shared__ uint32_t s_staged;                       // matcher waves whose share of the GT rows is in LDS
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t d = (uint32_t)C + 1u;
+    if (tid < SWEEP_SW) s_done[tid] = 0u;
+    if (tid == SWEEP_SW) s_staged = 0u;
+    __syncthreads();
+    if (blockIdx.x >= pieces) return;
+    const uint32_t mine = (pieces - blockIdx.x + gridDim.x - 1u) / gridDim.x;      // pieces of this block: blockIdx.x + i * gridDim.x
+    if (wave < SWEEP_SW) {
+        __builtin_amdgcn_s_setprio(3);
+        const v4f_ z = {0.0f, 0.0f, 0.0f, 0.0f};
+        constexpr uint32_t PER = SWEEP_PIECE / SWEEP_SW / 256u;       // 16-byte stores per lane and piece
+        // pieces that SWEEP_VMK stores in flight can belong to, plus one: a wave whose share of the tensor's last
+        // piece lies beyond its end issues nothing for that piece
+        constexpr uint32_t LAG = ((uint32_t)SWEEP_VMK + PER - 1u) / PER + 1u;
+        static_assert(PER >= 1u && PER * 256u * SWEEP_SW == SWEEP_PIECE, "store waves must tile a piece with whole wave-wide stores");
+        const uint32_t off = wave * (SWEEP_PIECE / SWEEP_SW) + lane * 4u;
+        for (uint32_t i = 0; i < mine; ++i) {
+#pragma unroll
+            for (uint32_t k = 0; k < PER; ++k) {
+                const uint32_t f = (blockIdx.x + i * gridDim.x) * SWEEP_PIECE + off + k * 256u;
+                if (f + 3u < total) {
+                    __builtin_nontemporal_store(z, reinterpret_cast<v4f_ *>(out_lab + f));
+                } else {
+#pragma unroll
+                    for (uint32_t e = 0; e < 3u; ++e)
+                        if (f + e < total) out_lab[f + e] = 0.0f;
+                }
+            }
+            // stores complete in order: all but the last SWEEP_VMK of this wave have reached L2
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SWEEP_VMK) : "memory");
+            if (lane == 0u && i >= LAG) s_done[wave] = i + 1u - LAG;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0u) s_done[wave] = mine;
+        return;
+    }
+    int32_t *s_lab = reinterpret_cast<int32_t *>(s_gt + gt_rows);
+    if (GT_LDS) {
+        for (uint32_t r = tid - SWEEP_SW * WAVE; r < gt_rows; r += SWEEP_MW * WAVE) {
+            s_gt[r] = gt_boxes[r];
+            s_lab[r] = gt_labels ? gt_labels[r] : -1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0u) atomicAdd(&s_staged, 1u);
+        while (__hip_atomic_load(&s_staged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)SWEEP_MW) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    auto gt_row = [&](uint32_t idx) -> float4 { return GT_LDS ? s_gt[idx] : gt_boxes[idx]; };
+    const uint32_t mw = wave - SWEEP_SW;
+    const uint32_t j = lane >> 4, rr = lane & 15u;
+    // lane = (piece j of the batch, row rr of the piece): the row, or rows = none
+    auto locate = [&](uint32_t t, uint32_t &i, uint32_t &f0, uint32_t &f1) -> uint32_t {
+        i = t * 4u + j;
+        if (i >= mine) return rows;
+        f0 = (blockIdx.x + i * gridDim.x) * SWEEP_PIECE;
+        f1 = min(f0 + (uint32_t)SWEEP_PIECE, total);
+        const uint32_t R = f0 / d + rr;                           // the piece's first row begins at or before f0
+        return (R < rows && R * d < f1) ? R : rows;
+    };
+    uint32_t i_n, f0_n, f1_n;
+    uint32_t R_n = locate(mw, i_n, f0_n, f1_n);
+    float4 a_n = anchors[R_n < rows ? R_n % (uint32_t)N : 0u];
+    for (uint32_t t = mw; t * 4u < mine; t += SWEEP_MW) {
+        const uint32_t i = i_n, f0 = f0_n, f1 = f1_n, R = R_n;
+        const float4 a = a_n;
+        R_n = locate(t + SWEEP_MW, i_n, f0_n, f1_n);             // the next batch's anchors travel under this batch's match
+        a_n = anchors[R_n < rows ? R_n % (uint32_t)N : 0u];
+        if (R >= rows) continue;
+        const uint32_t b = R / (uint32_t)N;
+        const float a_area = (a.w - a.y) * (a.z - a.x);                       // bndbox.py:285
+        const uint32_t gbase = b * (uint32_t)G;
+        // ---- argmax_g IoU (anchors.py:253-256): padded rows count as -1, strict >, first maximum wins ----
+        float best_iou = -INFINITY;
+        int best = 0;
+        for (int g0 = 0; g0 < G; g0 += 4) {
+            float4 gb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gb[k] = gt_row(gbase + (uint32_t)min(g0 + k, G - 1));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float area = (gb[k].w - gb[k].y) * (gb[k].z - gb[k].x);                     // bndbox.py:286
+                const bool pad = fmaxf(fmaxf(gb[k].x, gb[k].y), fmaxf(gb[k].z, gb[k].w)) < 0.0f;  // bndbox.py:295
+                const float v = pad ? -1.0f : pair_iou(a, a_area, gb[k], area);
+                if (g0 + k < G && v > best_iou) { best_iou = v; best = g0 + k; }
+            }
+        }
+        // ---- states, label (the second phase of match_tile, expression for expression) ----
+        const bool positive = best_iou >= pos_thr;                            // anchors.py:267
+        bool ignore = ((best_iou > neg_thr) && !positive) || (best_iou < 0.0f);   // :270-272
+        const float xc = (a.x + a.z) / 2.0f;                                  // :178-184
+        const float yc = (a.y + a.w) / 2.0f;
+        ignore = ignore || (xc >= img_w) || (yc >= img_h);
+        const int state = ignore ? -1 : (positive ? 1 : 0);
+        int label = -1;
+        if (positive && !ignore && gt_labels) label = GT_LDS ? s_lab[gbase + best] : gt_labels[gbase + best];
+        if (label < 0 || label >= C) label = -1;                              // tf.one_hot: zero row
+        const uint32_t e0 = R * d;
+        if (e0 >= f0) {                      // the row begins in this piece: its compact outputs and regression row are this lane's
+            if (out_idx) out_idx[R] = best;
+            if (out_state) out_state[R] = (int8_t)state;
+            if (out_iou) out_iou[R] = best_iou;
+            if (out_reg) {                                                    // anchors.py:286-297
+                const float4 g = gt_row(gbase + best);
+                const float aw = a.z - a.x, ah = a.w - a.y;
+                // one 20-byte row per lane, 4-byte aligned: two stores (dwordx3 + dwordx2) instead of five
+                struct __attribute__((packed, aligned(4))) Row5 { float v[5]; } r5;
+                r5.v[0] = (((g.x - a.x) / aw) - 0.0f) / 0.2f;
+                r5.v[1] = (((g.y - a.y) / ah) - 0.0f) / 0.2f;
+                r5.v[2] = (((g.z - a.z) / aw) - 0.0f) / 0.2f;
+                r5.v[3] = (((g.w - a.w) / ah) - 0.0f) / 0.2f;
+                r5.v[4] = (float)state;
+                *reinterpret_cast<Row5 *>(out_reg + (size_t)R * 5) = r5;
+            }
+        }
+        // ---- the non-zero label elements of this row that lie in this piece, behind the piece's zeros ----
+        const uint32_t ps = e0 + d - 1u;
+        const uint32_t pl = e0 + (uint32_t)max(label, 0);
+        const bool want_s = state != 0 && ps >= f0 && ps < f1;
+        const bool want_l = label >= 0 && pl >= f0 && pl < f1;
+        if (want_s || want_l) {
+            bool ok;
+            do {
+                ok = true;
+#pragma unroll
+                for (int w = 0; w < SWEEP_SW; ++w) ok = ok && s_done[w] > i;
+                if (!ok) __builtin_amdgcn_s_sleep(2);
+            } while (!ok);
+            if (want_s) out_lab[ps] = (float)state;
+            if (want_l) out_lab[pl] = 1.0f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Fused matcher + loss: the consumer of the targets, metric.py:97-123
 // (ModelMetric.__call__) with focal_loss (metric.py:9-38) and tf.keras.losses.Huber, evaluated
 // straight from (match, state, offsets) -- the one-hot [B,N,C+1] tensor (90 % of the bytes of
@@ -1130,6 +1325,42 @@ __global__ __launch_bounds__(256) void transform_kernel(const float4 *__restrict
                          (((g.z - a.z) / aw) - 0.0f) / 0.2f, (((g.w - a.w) / ah) - 0.0f) / 0.2f);
 }
 
+// tuning hooks of this unit (ODBOX_SWEEP*): read only in a build made with ODBOX_TUNING_HOOKS=1, like odbox_infer.hip's
+inline const char *train_tuning_env(const char *name)
+{
+#ifdef ODBOX_TUNING_HOOKS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
+int train_cu_count()
+{
+    static thread_local int cached_dev = -1, cached_cus = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        cached_dev = dev;
+        cached_cus = cus;
+    }
+    return cached_cus;
+}
+
+// does a streamed launch of odbox_match_encode take match_encode_sweep_kernel?
+bool sweep_applies(uint64_t label_bytes, int G, uint32_t d, bool labels_aligned16, bool gt_best)
+{
+    bool sweep = label_bytes > 0 && !gt_best && labels_aligned16 && G <= SWEEP_MAX_G &&
+                 (SWEEP_PIECE + d - 1u) / d + 1u <= (uint32_t)SWEEP_RPP &&
+                 label_bytes / sizeof(float) <= 0xffffffffull - 4u * SWEEP_PIECE &&
+                 label_bytes <= ((uint64_t)(train_tuning_env("ODBOX_SWEEP_MAX_MB") ? atoi(train_tuning_env("ODBOX_SWEEP_MAX_MB")) : ODBOX_SWEEP_MAX_MB) << 20);
+    if (const char *e = train_tuning_env("ODBOX_SWEEP")) sweep = sweep && atoi(e) != 0;
+    return sweep;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1214,6 +1445,26 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
                            neg_thr, pos_thr, out_regression, out_labels, out_match_idx, out_state, out_max_iou,
                            keys, (uint32_t)tiles, remap);
     };
+    // streamed wide-row labels with a short GT list: the lockstep sweep (match_encode_sweep_kernel)
+    const uint64_t total_floats = label_bytes / sizeof(float);
+    const bool sweep = stream_out && sweep_applies(label_bytes, G, d, aligned16(out_labels), keys != nullptr);
+    if (sweep) {
+        const uint32_t pieces = (uint32_t)((total_floats + SWEEP_PIECE - 1) / SWEEP_PIECE);
+        uint32_t grid = 2u * (uint32_t)train_cu_count();
+        if (const char *e = train_tuning_env("ODBOX_SWEEP_GRID")) grid = atoi(e) > 0 ? (uint32_t)atoi(e) : grid;
+        if (grid > pieces) grid = pieces;
+        bool gt_lds = bg <= (uint32_t)SWEEP_LDS_ROWS && (uint64_t)B * (uint64_t)G <= (uint64_t)SWEEP_LDS_ROWS;
+        if (const char *e = train_tuning_env("ODBOX_SWEEP_GT_LDS")) gt_lds = gt_lds && atoi(e) != 0;
+        auto sweep_launch = [&](auto kernel, size_t lds) {
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(WAVE * (SWEEP_SW + SWEEP_MW)), lds, (hipStream_t)stream,
+                               (const float4 *)anchors, (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w, neg_thr,
+                               pos_thr, out_regression, out_labels, out_match_idx, out_state, out_max_iou,
+                               (uint32_t)((uint64_t)B * N), (uint32_t)total_floats, pieces, bg);
+        };
+        if (gt_lds) sweep_launch(match_encode_sweep_kernel<true>, (size_t)bg * 20);
+        else sweep_launch(match_encode_sweep_kernel<false>, 0);
+        return launch_status("match_encode_sweep");
+    }
     if (!keys) {
         if (stream_out) launch(match_encode_kernel<true, false>);
         else launch(match_encode_kernel<false, false>);
@@ -1228,6 +1479,18 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
     hipLaunchKernelGGL(gt_best_finalize_kernel, dim3((bg + 255u) / 256u), dim3(256), 0, (hipStream_t)stream,
                        (const float4 *)anchors, (const float4 *)gt_boxes, N, G, keys, bg);
     return launch_status("gt_best_finalize");
+}
+
+int odbox_match_encode_plan(int B, int N, int G, int C, int labels_aligned16, int want_gt_best)
+{
+    if (B < 1 || N < 1 || G < 1 || C < 1 || C > ODBOX_MAX_CLASSES)
+        return fail(ODBOX_EINVAL, "odbox_match_encode_plan: bad shape B=%d N=%d G=%d C=%d", B, N, G, C);
+    const uint32_t d = (uint32_t)C + 1u;
+    const uint64_t label_bytes = (uint64_t)B * (uint64_t)N * d * sizeof(float);
+    const int policy = g_output_policy.load(std::memory_order_relaxed);
+    const bool stream_out = policy == ODBOX_POLICY_STREAM || (policy == ODBOX_POLICY_AUTO && label_bytes > ((uint64_t)ODBOX_STREAM_MB << 20));
+    if (!stream_out) return ODBOX_PLAN_TILES;
+    return sweep_applies(label_bytes, G, d, labels_aligned16 != 0, want_gt_best != 0) ? ODBOX_PLAN_SWEEP : ODBOX_PLAN_TILES_STREAM;
 }
 
 size_t odbox_match_loss_workspace(int B, int N)
