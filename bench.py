@@ -172,6 +172,15 @@ def per_step_median(fn, groups=10, per_group=10):
     return statistics.median(ts), min(ts)
 
 
+PLAN_KERNELS = {0: 'match_encode_kernel<false, false>', 1: 'match_encode_kernel<true, false>',
+                2: 'match_encode_sweep_kernel<true>'}
+
+
+def match_encode_kernel_name(lib, B, N, G, C):
+    """The kernel odbox_match_encode launches for this shape under the output policy in force (odbox_match_encode_plan)."""
+    return PLAN_KERNELS.get(lib.odbox_match_encode_plan(B, N, G, C, 1, 0), 'match_encode_kernel')
+
+
 def hbm_roofline(kernel, byts, mean_s, median_s, traffic_key=None, **extra):
     ach = byts / mean_s / 1e9
     r = {'bound': 'hbm', 'kernel': kernel, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -293,10 +302,12 @@ def main():
     # (odbox_set_output_policy, anchors.set_output_policy('stream')); the library's size rule alone
     # (`auto`) would send 221 MB of labels through them
     lib.odbox_set_output_policy(2)
+    k_stream = match_encode_kernel_name(lib, B, N, G, C)
     wall, ev = timed(step, args.steps, args.warmup, world)
     med, _ = per_step_median(step)
     img_s = world * B * args.steps / wall
     lib.odbox_set_output_policy(0)
+    k_auto = match_encode_kernel_name(lib, B, N, G, C)
     _, ev0 = timed(step, args.steps, args.warmup, 1)                   # the same rotation under the default policy
     med0, _ = per_step_median(step)
     # the same launch rewriting ONE output set every step: its 245 MB fit the Infinity Cache
@@ -323,14 +334,14 @@ def main():
                                % (N, C, G, B, OUTPUT_SETS, OUTPUT_SETS * B * N * (C + 6) * 4 / 1e9),
                    'global_batch': world * B, 'anchors': N, 'classes': C, 'gt_per_image': G,
                    'parallelism': 'images sharded over %d GPU(s), no collective' % world},
-        'roofline': hbm_roofline('match_encode_kernel', w['bytes'], ev / args.steps, med, 'match_encode_kernel_rotating',
+        'roofline': hbm_roofline(k_stream, w['bytes'], ev / args.steps, med, 'match_encode_kernel_rotating',
                                  output_sets=OUTPUT_SETS, output_policy='stream'),
         'roofline_auto_policy': hbm_roofline(
-            'match_encode_kernel', w['bytes'], ev0 / args.steps, med0, None, output_sets=OUTPUT_SETS, output_policy='auto',
+            k_auto, w['bytes'], ev0 / args.steps, med0, None, output_sets=OUTPUT_SETS, output_policy='auto',
             note='the same rotation under the default policy (through the caches up to 512 MB of labels): what a caller '
                  'that says nothing about its consumer gets on cold buffers'),
         'roofline_cache_resident': hbm_roofline(
-            'match_encode_kernel', w['bytes'], ev1 / args.steps, med1, 'match_encode_kernel', output_policy='auto',
+            k_auto, w['bytes'], ev1 / args.steps, med1, 'match_encode_kernel', output_policy='auto',
             note='one output set rewritten every step: the 245 MB of stores fit the 256 MB Infinity Cache, so this is '
                  'a cache-assisted store rate, not an HBM fraction'),
     }
@@ -353,6 +364,7 @@ def main():
                 anch = A.generate_anchors(A.AnchorsConfig(), workloads.CONFIGS[cfg]['S'])
             stepc, wc = match_encode_case(lib, dev, stream, cfg, Bc, anch, 1000 + cfg + 7919 * rank, sets)
             lib.odbox_set_output_policy(2 if sets > 2 else 0)           # rotating (cold) outputs: written around the caches
+            k_cfg = match_encode_kernel_name(lib, Bc, wc['N'], wc['G'], wc['C'])
             wl, el = timed(stepc, ksteps, 3, world)
             medc, _ = per_step_median(stepc, per_group=5)
             lib.odbox_set_output_policy(0)
@@ -362,7 +374,7 @@ def main():
                 # VALU-bound: 500 GT rows per anchor.  The kernel proves most pairs zero without
                 # evaluating them, so "pairs / peak rate" is not a fraction of anything; the defensible figure is
                 # how busy the VALUs are over the launch (SQ counters, collected in their own PMC passes).
-                sub['roofline'] = {'bound': 'valu', 'kernel': 'match_encode_kernel', 'us_per_launch': round(el / ksteps * 1e6, 2),
+                sub['roofline'] = {'bound': 'valu', 'kernel': k_cfg, 'us_per_launch': round(el / ksteps * 1e6, 2),
                                    'us_per_launch_median': round(medc * 1e6, 2),
                                    'bytes_per_launch': wc['bytes'],
                                    'hbm_frac': round(wc['bytes'] / (el / ksteps) / 1e9 / HBM_PEAK_GBS, 4),
@@ -370,7 +382,7 @@ def main():
                                    'frac_source': 'static: VALU-busy cycles / launch cycles from the SQ counter passes '
                                                   '(tools/pmc_cfg.sh 4, profiles/), not measured in this run'}
             else:
-                sub['roofline'] = hbm_roofline('match_encode_kernel', wc['bytes'], el / ksteps, medc, None, output_sets=sets,
+                sub['roofline'] = hbm_roofline(k_cfg, wc['bytes'], el / ksteps, medc, None, output_sets=sets,
                                                output_policy='stream' if sets > 2 else 'auto')
             result[key] = sub
             del stepc, wc

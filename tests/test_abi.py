@@ -207,6 +207,17 @@ def test_every_entry_rejects_bad_arguments_without_touching_the_gpu(lib):
     # the output policy is a process-wide setting: unknown values are refused, a valid call returns the previous one
     assert lib.odbox_set_output_policy(7) == -1 and b'odbox_set_output_policy' in lib.odbox_last_error()
     assert lib.odbox_set_output_policy(2) == 0 and lib.odbox_set_output_policy(0) == 2
+    # which kernel a dense match+encode takes is host logic (odbox_match_encode_plan: 0 tiles, 1 streamed tiles, 2 sweep)
+    assert lib.odbox_match_encode_plan(64, 10647, 20, 80, 1, 0) == 0               # 221 MB of labels under AUTO: through the caches
+    assert lib.odbox_match_encode_plan(160, 10647, 20, 80, 1, 0) == 2              # 552 MB: streamed, wide rows, short GT list
+    assert lib.odbox_match_encode_plan(32, 196416, 20, 80, 1, 0) == 1              # 2 GB: streamed tiles
+    assert lib.odbox_match_encode_plan(128, 49104, 500, 1, 1, 0) == 0
+    assert lib.odbox_set_output_policy(2) == 0
+    assert [lib.odbox_match_encode_plan(64, 10647, 20, 80, a, g) for a, g in ((1, 0), (0, 0), (1, 1))] == [2, 1, 1]
+    assert lib.odbox_match_encode_plan(64, 10647, 65, 80, 1, 0) == 1 and lib.odbox_match_encode_plan(64, 10647, 20, 67, 1, 0) == 1
+    assert lib.odbox_match_encode_plan(128, 49104, 500, 1, 1, 0) == 1
+    assert lib.odbox_set_output_policy(0) == 2
+    assert lib.odbox_match_encode_plan(0, 1, 1, 1, 1, 0) == -1 and b'odbox_match_encode_plan' in lib.odbox_last_error()
     # empty problems are successes, decided before any pointer is looked at
     assert lib.odbox_anchor_tile(None, 9, 0, 4, 8.0, None, None) == 0
     assert lib.odbox_clip_boxes(None, 0, 8.0, 8.0, None, None) == 0

@@ -38,7 +38,7 @@ for sub in ('stream', 'auto', 'resident', 'rest'):
                     for k, pat in REST:
                         if pat in name:
                             vals[k][r['Counter_Name']].append(float(r['Counter_Value']))
-                elif 'match_encode_kernel' in name:
+                elif 'match_encode_kernel' in name or 'match_encode_sweep_kernel' in name:
                     vals[HEAD[sub]][r['Counter_Name']].append(float(r['Counter_Value']))
 path = 'profiles/pmc_traffic.json'
 try:
