@@ -433,3 +433,20 @@ def test_16bit_full_configs4_share_against_the_fp32_path():
         for x, y in zip(got, want):
             assert torch.equal(x, y)
         assert int(got[4].min()) > 0
+
+
+def test_tensorflows_own_nms_unit_test_vectors_on_the_gpu():
+    """Row a11: the keep-lists of TensorFlow's own NonMaxSuppressionV3 unit tests (tests/golden/tf_nms_vectors.json)
+    through odbox_decode_nms as a one-class problem: selection order, flipped corners, score threshold, output cap,
+    identical boxes."""
+    import json
+    import os
+    doc = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'tf_nms_vectors.json')))
+    for name, (boxes, scores, max_out, iou_thr, score_thr, want) in doc['cases'].items():
+        xyxy = np.float32(boxes)[None][..., [1, 0, 3, 2]]
+        sc = np.float32(scores)[None, :, None]
+        b, s, l, keep, count = BB.nms(xyxy, sc, score_threshold=score_thr, iou_threshold=iou_thr, max_ret=max_out, return_keep=True)
+        n = int(cpu(count)[0])
+        assert cpu(keep)[0, :n].tolist() == want, name
+        np.testing.assert_array_equal(cpu(b)[0, :n], xyxy[0][want])
+        np.testing.assert_array_equal(cpu(s)[0, :n], np.float32(scores)[want])

@@ -292,3 +292,41 @@ def test_gt_best_anchor_known_answers_and_two_restatements_agree():
     i2, v2 = c_oracle.gt_best(a, g, threads=2)
     np.testing.assert_array_equal(i1, i2)
     np.testing.assert_array_equal(v1, v2)
+
+
+def tf_nms_cases():
+    import json
+    import os
+    doc = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'tf_nms_vectors.json')))
+    return doc['cases']
+
+
+def test_tf_nms_restatement_against_tensorflows_own_unit_test_vectors():
+    """Row a11: TensorFlow's NonMaxSuppressionV3 is a third-party kernel that is absent here; its restatement
+    (oracle tf_non_max_suppression) is pinned by the known answers of TensorFlow's own unit tests
+    (tests/golden/tf_nms_vectors.json names the source)."""
+    for name, (boxes, scores, max_out, iou_thr, score_thr, want) in tf_nms_cases().items():
+        got = O.tf_non_max_suppression(np.float32(boxes), np.float32(scores), max_out, iou_thr, score_thr)
+        assert got.tolist() == want, name
+        # the same vector through the whole oracle nms() (one class, xyxy columns) and its C twin
+        xyxy = np.float32(boxes)[None][..., [1, 0, 3, 2]]
+        sc = np.float32(scores)[None, :, None]
+        _, _, _, keep, count = O.nms(xyxy, sc, score_thr, iou_thr, max_out)
+        assert keep[0, :count[0]].tolist() == want, name
+        _, _, _, keep, count = c_oracle.decode_nms(None, xyxy, sc, (200, 200), do_clip=False, score_threshold=score_thr,
+                                                   iou_threshold=iou_thr, max_ret=max_out)
+        assert keep[0, :count[0]].tolist() == want, name
+
+
+def test_huber_restatement_against_the_keras_docstring_values():
+    """tf.keras.losses.Huber is third party (call site metric.py:99); the restatement is held to the values its
+    published docstring prints (tests/golden/keras_huber_vectors.json names the source)."""
+    import json
+    import os
+    v = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'keras_huber_vectors.json')))
+    per_sample = O.huber(F(v['y_true']), F(v['y_pred']), v['delta'])
+    np.testing.assert_allclose(per_sample, v['reduction_none'], atol=5e-4)           # exact: 0.5*(0.36+0.36)/2, 0.5*(0.16+0.36)/2
+    np.testing.assert_allclose(per_sample, [0.18, 0.13], rtol=1e-6)
+    assert abs(per_sample.sum() - v['reduction_sum']) < 5e-4
+    assert abs(per_sample.mean() - v['reduction_sum_over_batch_size']) < 5e-4
+    assert abs((per_sample * [1, 0]).mean() - v['sample_weight_1_0']) < 5e-4
