@@ -42,12 +42,14 @@ int odbox_version(void);
 const char *odbox_last_error(void);
 
 /* How odbox_match_encode writes its dense outputs (no counterpart in the reference: a property of this
- * GPU's memory system).  AUTO (default): through the caches while the label tensor is at most 512 MB
- * -- right when the consumer reads the targets next, or when one buffer is rewritten every step (it is
- * still in the 256 MB Infinity Cache) -- and around them (nontemporal stores) beyond.  CACHE / STREAM
- * force one or the other; STREAM is for outputs nothing reads soon (targets computed ahead by the
- * input pipeline into a fresh buffer every call).  Process-wide; returns the previous policy, or
- * ODBOX_EINVAL.  Results are bit-identical under every policy. */
+ * GPU's memory system).  Through the caches is right when the stores land in lines the 256 MB Infinity Cache
+ * still holds (one buffer rewritten call after call) or when the consumer reads the targets next; around
+ * them (nontemporal stores) when the buffer is fresh or large.  AUTO (default) decides per call: labels beyond
+ * 512 MB go around the caches; label-stream shapes (those the lockstep sweep serves, see
+ * odbox_match_encode_plan) go around them too UNLESS this very buffer was written by a call of the last 2 ms
+ * and the bytes the library has written since fit the cache; everything else goes through.  CACHE / STREAM
+ * force one or the other.  Process-wide; returns the previous policy, or ODBOX_EINVAL.  Results are
+ * bit-identical under every policy. */
 #define ODBOX_POLICY_AUTO   0
 #define ODBOX_POLICY_CACHE  1
 #define ODBOX_POLICY_STREAM 2
@@ -59,12 +61,15 @@ int odbox_set_output_policy(int policy);
  * 64-anchor tiles, nontemporal stores.  SWEEP: streamed outputs with wide label rows (C + 1 >= 69), at
  * most 64 GT rows, 16-byte aligned labels, no per-GT output and at most 768 MB of labels: the label tensor
  * is written as one chip-wide lockstep sweep of 4 KB pieces by dedicated store waves while other waves
- * of the same blocks match and patch (the fastest order into cold HBM).  Returns ODBOX_EINVAL on a bad
- * shape. */
+ * of the same blocks match and patch (the fastest order into cold HBM).  Under AUTO the answer is the one
+ * for a buffer that no recent call wrote.  Returns ODBOX_EINVAL on a bad shape.
+ * odbox_match_encode_last_plan: the plan the calling thread's last odbox_match_encode actually took
+ * (-1 before the first call). */
 #define ODBOX_PLAN_TILES        0
 #define ODBOX_PLAN_TILES_STREAM 1
 #define ODBOX_PLAN_SWEEP        2
 int odbox_match_encode_plan(int B, int N, int G, int C, int labels_aligned16, int want_gt_best);
+int odbox_match_encode_last_plan(void);
 
 /* anchors.py:44-87 AnchorGenerator.tile_anchors_over_feature_map:
  * out[(i*fw + j)*A + a] = base[a] + ((j+.5)*stride, (i+.5)*stride, (j+.5)*stride, (i+.5)*stride). */

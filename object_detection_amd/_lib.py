@@ -24,6 +24,7 @@ SIGNATURES = {
     'odbox_last_error': (ctypes.c_char_p, []),
     'odbox_set_output_policy': (_i, [_i]),
     'odbox_match_encode_plan': (_i, [_i, _i, _i, _i, _i, _i]),
+    'odbox_match_encode_last_plan': (_i, []),
     'odbox_anchor_tile': (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),
     'odbox_match_encode': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'odbox_match_loss_workspace': (_sz, [_i, _i]),

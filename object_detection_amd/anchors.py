@@ -113,6 +113,11 @@ def match_encode_plan(batch: int, num_anchors: int, num_gt: int, num_classes: in
     return _PLANS[rc]
 
 
+def match_encode_last_plan():
+    """The kernel this thread's last `match_encode` / `anchor_targets_bbox` call really launched, or None."""
+    return _PLANS.get(_lib.load().odbox_match_encode_last_plan())
+
+
 def match_encode(anchors, image_hw, bndboxes, labels, num_classes,
                  negative_overlap=0.4, positive_overlap=0.5,
                  dense=True, compact=False, gt_best=False):

@@ -10,6 +10,7 @@
 // Reference citations are file:line under the reference tree (bioothod/object_detection).
 #include "odbox_common.h"
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <type_traits>
 
@@ -1350,6 +1351,53 @@ int train_cu_count()
     return cached_cus;
 }
 
+// ---- ODBOX_POLICY_AUTO: is the label buffer of this call still in the Infinity Cache? --------------------------
+// Through the caches a launch is 1.2x faster when its stores land in lines the 256 MB Infinity Cache still holds (one
+// buffer rewritten call after call: configs[1] 33.5 us against 40 us around the caches) and 1.25x SLOWER when they do
+// not (a fresh or rotating buffer: 49.6 against 39.5 us; same-box table in profiles/README.md, tools/exp_policy.py).
+// The library sees every dense output it writes, so AUTO keeps the last few (pointer, bytes, time) per device, most
+// recent first, and calls a buffer resident when it was written a moment ago and the bytes written since -- its own
+// included -- fit the cache: the reuse distance of an LRU cache.  The time bound stands for everything the library
+// does NOT see: a training step between two calls streams gigabytes through the cache, and at 6 TB/s 256 MB last 40 us.
+constexpr uint64_t MALL_BYTES = 256ull << 20;
+constexpr int RECENT_OUTS = 16;
+constexpr std::chrono::microseconds RECENT_WINDOW{2000};
+struct RecentOut {
+    const void *ptr;
+    uint64_t bytes;
+    int dev;
+    std::chrono::steady_clock::time_point when;
+};
+std::mutex g_recent_mu;
+RecentOut g_recent[RECENT_OUTS];
+int g_recent_n = 0;
+
+bool recently_written(const void *ptr, uint64_t bytes)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const auto now = std::chrono::steady_clock::now();
+    std::lock_guard<std::mutex> lock(g_recent_mu);
+    uint64_t distance = bytes;
+    bool resident = false;
+    int at = g_recent_n < RECENT_OUTS ? g_recent_n : RECENT_OUTS - 1;      // slot that is dropped (or the new one)
+    for (int i = 0; i < g_recent_n; ++i) {
+        if (g_recent[i].dev != dev) continue;
+        if (g_recent[i].ptr == ptr) {
+            resident = g_recent[i].bytes == bytes && distance <= MALL_BYTES && now - g_recent[i].when <= RECENT_WINDOW;
+            at = i;
+            break;
+        }
+        distance += g_recent[i].bytes;
+    }
+    if (at == g_recent_n) ++g_recent_n;
+    for (int i = at; i > 0; --i) g_recent[i] = g_recent[i - 1];
+    g_recent[0] = RecentOut{ptr, bytes, dev, now};
+    return resident;
+}
+
+thread_local int g_last_plan = -1;      // odbox_match_encode_last_plan
+
 // does a streamed launch of odbox_match_encode take match_encode_sweep_kernel?
 bool sweep_applies(uint64_t label_bytes, int G, uint32_t d, bool labels_aligned16, bool gt_best)
 {
@@ -1417,8 +1465,14 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
     // through the caches even when they would fit -- configs[1] into cold buffers: 50.2 us through the
     // caches, 43.6 us around them; rewriting ONE buffer in place: 33.2 us against 43.6 us.
     const int policy = g_output_policy.load(std::memory_order_relaxed);
-    const bool stream_out = label_bytes > 0 && (policy == ODBOX_POLICY_STREAM ||
-                                                (policy == ODBOX_POLICY_AUTO && label_bytes > ((uint64_t)ODBOX_STREAM_MB << 20)));
+    bool stream_out = label_bytes > 0 && (policy == ODBOX_POLICY_STREAM ||
+                                          (policy == ODBOX_POLICY_AUTO && label_bytes > ((uint64_t)ODBOX_STREAM_MB << 20)));
+    // AUTO below the size rule, for the shapes the sweep serves (a label stream with a cheap match): around the caches
+    // unless this very buffer was written a moment ago and is still in the Infinity Cache (recently_written)
+    if (policy == ODBOX_POLICY_AUTO && !stream_out && sweep_applies(label_bytes, G, d, aligned16(out_labels), out_gt_best != nullptr)) {
+        const uint64_t out_bytes = label_bytes + (out_regression ? (uint64_t)B * (uint64_t)N * 5u * sizeof(float) : 0u);
+        stream_out = !recently_written(out_labels, out_bytes);
+    }
 #ifdef ODBOX_ENC_REMAP_FORCE
     const uint32_t remap = ODBOX_ENC_REMAP_FORCE;
 #else
@@ -1463,8 +1517,10 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
         };
         if (gt_lds) sweep_launch(match_encode_sweep_kernel<true>, (size_t)bg * 20);
         else sweep_launch(match_encode_sweep_kernel<false>, 0);
+        g_last_plan = ODBOX_PLAN_SWEEP;
         return launch_status("match_encode_sweep");
     }
+    g_last_plan = stream_out ? ODBOX_PLAN_TILES_STREAM : ODBOX_PLAN_TILES;
     if (!keys) {
         if (stream_out) launch(match_encode_kernel<true, false>);
         else launch(match_encode_kernel<false, false>);
@@ -1489,9 +1545,13 @@ int odbox_match_encode_plan(int B, int N, int G, int C, int labels_aligned16, in
     const uint64_t label_bytes = (uint64_t)B * (uint64_t)N * d * sizeof(float);
     const int policy = g_output_policy.load(std::memory_order_relaxed);
     const bool stream_out = policy == ODBOX_POLICY_STREAM || (policy == ODBOX_POLICY_AUTO && label_bytes > ((uint64_t)ODBOX_STREAM_MB << 20));
+    const bool sweep = sweep_applies(label_bytes, G, d, labels_aligned16 != 0, want_gt_best != 0);
+    if (policy == ODBOX_POLICY_AUTO && !stream_out) return sweep ? ODBOX_PLAN_SWEEP : ODBOX_PLAN_TILES;      // a buffer not written a moment ago
     if (!stream_out) return ODBOX_PLAN_TILES;
-    return sweep_applies(label_bytes, G, d, labels_aligned16 != 0, want_gt_best != 0) ? ODBOX_PLAN_SWEEP : ODBOX_PLAN_TILES_STREAM;
+    return sweep ? ODBOX_PLAN_SWEEP : ODBOX_PLAN_TILES_STREAM;
 }
+
+int odbox_match_encode_last_plan(void) { return g_last_plan; }
 
 size_t odbox_match_loss_workspace(int B, int N)
 {

@@ -208,7 +208,9 @@ def test_every_entry_rejects_bad_arguments_without_touching_the_gpu(lib):
     assert lib.odbox_set_output_policy(7) == -1 and b'odbox_set_output_policy' in lib.odbox_last_error()
     assert lib.odbox_set_output_policy(2) == 0 and lib.odbox_set_output_policy(0) == 2
     # which kernel a dense match+encode takes is host logic (odbox_match_encode_plan: 0 tiles, 1 streamed tiles, 2 sweep)
-    assert lib.odbox_match_encode_plan(64, 10647, 20, 80, 1, 0) == 0               # 221 MB of labels under AUTO: through the caches
+    assert lib.odbox_match_encode_plan(64, 10647, 20, 80, 1, 0) == 2               # AUTO, a label-stream shape, a buffer no recent call wrote
+    assert lib.odbox_match_encode_plan(64, 10647, 20, 80, 0, 0) == 0 and lib.odbox_match_encode_plan(64, 10647, 65, 80, 1, 0) == 0
+    assert lib.odbox_match_encode_last_plan() == -1                                # no call yet on this thread
     assert lib.odbox_match_encode_plan(160, 10647, 20, 80, 1, 0) == 2              # 552 MB: streamed, wide rows, short GT list
     assert lib.odbox_match_encode_plan(32, 196416, 20, 80, 1, 0) == 1              # 2 GB: streamed tiles
     assert lib.odbox_match_encode_plan(128, 49104, 500, 1, 1, 0) == 0

@@ -103,8 +103,11 @@ def test_what_takes_the_sweep(stream_policy):
     assert A.match_encode_plan(64, 10647, 20, 80, gt_best=True) == 'tiles_stream'
     assert A.match_encode_plan(32, 196416, 20, 80) == 'tiles_stream'           # 2 GB of labels: tiles win there
     A.set_output_policy('auto')
+    assert A.match_encode_plan(64, 10647, 20, 80) == 'sweep'                   # AUTO: a buffer that no recent call wrote
+    assert A.match_encode_plan(64, 10647, 65, 80) == 'tiles'
+    assert A.match_encode_plan(160, 10647, 20, 80) == 'sweep'                  # beyond 512 MB AUTO always streams
+    A.set_output_policy('cache')
     assert A.match_encode_plan(64, 10647, 20, 80) == 'tiles'
-    assert A.match_encode_plan(160, 10647, 20, 80) == 'sweep'                  # beyond 512 MB AUTO streams
     with pytest.raises(_lib.OdboxError):
         A.match_encode_plan(1, 1, 0, 80)
 
@@ -223,3 +226,41 @@ def test_repeated_calls_into_dirty_buffers(stream_policy):
         ref = c_oracle.match_encode(anchors, (416, 416), gt, lab, C, threads=8)
         np.testing.assert_array_equal(cpu(lab_out), ref['labels'])
         np.testing.assert_array_equal(cpu(reg_out)[..., 4], ref['regression'][..., 4])
+
+
+def test_auto_policy_follows_the_reuse_distance_of_the_buffer():
+    """ODBOX_POLICY_AUTO: a label buffer goes through the caches only when this very buffer was written a moment ago
+    and the bytes written since fit the 256 MB Infinity Cache; fresh, rotating or long-untouched buffers take the
+    sweep.  The bits are the same either way."""
+    import time
+    lib = _lib.load()
+    dev = torch.device('cuda')
+    assert A.set_output_policy('auto') == 'auto'
+    anchors = O.yolo_shaped_anchors(416)
+    N, C, B = anchors.shape[0], 80, 24                                  # 83 MB of labels per buffer
+    gt, lab = workloads.match_inputs(2, batch=B)
+    a, g_, l_ = (torch.as_tensor(x).to(dev) for x in (anchors, gt, lab))
+    bufs = [torch.empty((B, N, C + 1), device=dev) for _ in range(4)]
+    regs = [torch.empty((B, N, 5), device=dev) for _ in range(4)]
+
+    def call(k):
+        rc = lib.odbox_match_encode(a.data_ptr(), g_.data_ptr(), l_.data_ptr(), B, N, gt.shape[1], C, 416.0, 416.0, 0.4, 0.5,
+                                    regs[k].data_ptr(), bufs[k].data_ptr(), None, None, None, None, _lib.stream_ptr())
+        assert rc == 0, lib.odbox_last_error()
+        return A.match_encode_last_plan()
+
+    assert call(0) == 'sweep'                                           # never seen
+    assert [call(0) for _ in range(3)] == ['tiles'] * 3                 # rewritten in place: still in the cache
+    assert call(1) == 'sweep'
+    assert [call(k) for k in (0, 1, 0, 1)] == ['tiles'] * 4             # two buffers, 2 x 88 MB: both stay resident
+    assert [call(k) for k in (2, 3)] == ['sweep'] * 2
+    assert [call(k) for k in (0, 1, 2, 3)] == ['sweep'] * 4             # four in rotation: 352 MB between two writes of one
+    torch.cuda.synchronize()
+    time.sleep(0.02)
+    assert call(3) == 'sweep'                                           # written last, but 20 ms ago
+    assert call(3) == 'tiles'
+    torch.cuda.synchronize()
+    ref = c_oracle.match_encode(anchors, (416, 416), gt, lab, C, threads=8)
+    for k in range(4):
+        np.testing.assert_array_equal(cpu(bufs[k]), ref['labels'])
+        np.testing.assert_array_equal(cpu(regs[k])[..., 4], ref['regression'][..., 4])
