@@ -146,6 +146,40 @@ int main()
     printf("match_encode: %zu index/state/one-hot mismatches, %zu offsets beyond 1e-5 (%zu foreground anchors)\n", bad, bad_reg, fg);
     failures += bad + bad_reg + (fg == 0);
 
+    // ---- the same batch with 80 classes under ODBOX_POLICY_STREAM: the lockstep sweep (match_encode_sweep_kernel) --------
+    {
+        const int C2 = 80;
+        std::vector<int32_t> lab2(lab);
+        for (size_t i = 0; i < lab2.size(); ++i)
+            if (lab2[i] >= 0) lab2[i] = (int32_t)((lab2[i] * 13 + (int32_t)i) % C2);
+        std::vector<float> reg2((size_t)B * N * 5), lbl2((size_t)B * N * (C2 + 1)), reg2_ref(reg2.size()), lbl2_ref(lbl2.size());
+        std::vector<int32_t> midx2((size_t)B * N), midx2_ref(midx2.size());
+        std::vector<int8_t> state2((size_t)B * N), state2_ref(state2.size());
+        odbox_oracle_match_encode(anchors_ref.data(), gt.data(), lab2.data(), B, N, G, C2, (float)S, (float)S, 0.4f, 0.5f,
+                                  reg2_ref.data(), lbl2_ref.data(), midx2_ref.data(), state2_ref.data(), nullptr, 1);
+        int32_t *d_lab2 = to_device(lab2);
+        float *d_lbl2 = nullptr;
+        HIP_OK(hipMalloc((void **)&d_lbl2, lbl2.size() * sizeof(float)));
+        HIP_OK(hipMemset(d_lbl2, 0x7f, lbl2.size() * sizeof(float)));
+        const int prev = odbox_set_output_policy(ODBOX_POLICY_STREAM);
+        const int plan = odbox_match_encode_plan(B, N, G, C2, 1, 0);
+        ODBOX_OK(odbox_match_encode(d_anchors, d_gt, d_lab2, B, N, G, C2, (float)S, (float)S, 0.4f, 0.5f, d_reg, d_lbl2, d_midx,
+                                    d_state, nullptr, nullptr, st));
+        const int took = odbox_match_encode_last_plan();
+        odbox_set_output_policy(prev);
+        HIP_OK(hipStreamSynchronize(st));
+        if (!from_device(reg2, d_reg) || !from_device(lbl2, d_lbl2) || !from_device(midx2, d_midx) || !from_device(state2, d_state)) return 2;
+        size_t bad2 = (plan != ODBOX_PLAN_SWEEP) + (took != ODBOX_PLAN_SWEEP);
+        for (size_t i = 0; i < midx2.size(); ++i) { bad2 += midx2[i] != midx2_ref[i]; bad2 += state2[i] != state2_ref[i]; }
+        for (size_t i = 0; i < lbl2.size(); ++i) bad2 += lbl2[i] != lbl2_ref[i];
+        const size_t bad_reg2 = mismatches(reg2.data(), reg2_ref.data(), reg2.size(), 1e-5f);
+        printf("match_encode (sweep, plan %d, took %d): %zu index/state/one-hot mismatches, %zu offsets beyond 1e-5\n", plan, took, bad2,
+               bad_reg2);
+        failures += bad2 + bad_reg2;
+        HIP_OK(hipFree(d_lbl2));
+        HIP_OK(hipFree(d_lab2));
+    }
+
     // ---- decode + NMS (encoder.py:200-214, bndbox.py:117-252) ------------------------------------
     const int max_ret = 20;
     std::vector<float> rgs((size_t)B * N * 4), scores((size_t)B * N * C);
