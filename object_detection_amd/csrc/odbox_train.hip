@@ -572,21 +572,24 @@ constexpr int SWEEP_MAX_G = 64;
 #define ODBOX_SWEEP_MAX_MB 768
 #endif
 
-constexpr int SWEEP_LDS_ROWS = 3072;            // GT rows of the whole batch (B * G) a block can keep in LDS: 60 KB, two blocks per CU
+constexpr int SWEEP_LDS_ROWS = 3072;            // GT rows a block keeps in LDS (60 KB, two blocks per CU): the first SWEEP_LDS_ROWS / B of every image
+constexpr int SWEEP_MAX_B = 8192;               // one 16-bit row bound per image in LDS
 
-// GT_LDS: the batch's GT boxes and labels (B * G <= SWEEP_LDS_ROWS rows) are staged in LDS by the matcher
-// waves while the store waves already sweep; the argmax loop then reads LDS only.  Under the store stream a
-// global round trip costs microseconds, and the plain form pays G / 4 + 3 of them per batch of four pieces:
-// configs[1] into cold buffers 40.6 us without the staging (same-box A/B), against 43.5 us for the tiles.
-template <bool GT_LDS>
+// The matcher waves first look at the whole batch's GT rows once (one row per lane, G <= 64), while the store waves
+// already sweep: per image the BOUND = index behind its last valid row -- everything from there on is padding, which
+// the argmax loop never visits (the reference pads every image to 64 rows, detection.py:246-266, of which a handful
+// are boxes) and accounts for as one candidate of IoU -1 at index `bound`, exactly what visiting them in order gives
+// under strict > -- and the first gs = min(G, SWEEP_LDS_ROWS / B) rows of every image go to LDS with their labels.
+// Under the store stream a global round trip costs microseconds: the loop over LDS rows pays none (configs[1] into
+// cold buffers 39.1 us; with every row from global memory 39.9-40.7 us; 64-row padded GT before the bound: 55 us).
 __global__ __launch_bounds__(WAVE *(SWEEP_SW + SWEEP_MW)) void match_encode_sweep_kernel(
     const float4 *__restrict__ anchors, const float4 *__restrict__ gt_boxes, const int32_t *__restrict__ gt_labels, int N,
     int G, int C, float img_h, float img_w, float neg_thr, float pos_thr, float *__restrict__ out_reg, float *out_lab,
     int32_t *__restrict__ out_idx, int8_t *__restrict__ out_state, float *__restrict__ out_iou, uint32_t rows,
-    uint32_t total, uint32_t pieces, uint32_t gt_rows)
+    uint32_t total, uint32_t pieces, uint32_t B, uint32_t gs)
 {
     typedef float v4f_ __attribute__((ext_vector_type(4)));
-    extern __shared__ float4 s_gt[];                    // GT_LDS: [gt_rows] boxes, then [gt_rows] labels
+    extern __shared__ float4 s_gt[];                    // [B * gs] boxes, [B * gs] labels, [B] bounds
     __shared__ volatile uint32_t s_done[SWEEP_SW];      // store wave w: the zeros of this block's pieces < s_done[w] are in L2
     __shared__ uint32_t s_staged;                       // matcher waves whose share of the GT rows is in LDS
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
@@ -625,19 +628,47 @@ __global__ __launch_bounds__(WAVE *(SWEEP_SW + SWEEP_MW)) void match_encode_swee
         if (lane == 0u) s_done[wave] = mine;
         return;
     }
-    int32_t *s_lab = reinterpret_cast<int32_t *>(s_gt + gt_rows);
-    if (GT_LDS) {
-        for (uint32_t r = tid - SWEEP_SW * WAVE; r < gt_rows; r += SWEEP_MW * WAVE) {
-            s_gt[r] = gt_boxes[r];
-            s_lab[r] = gt_labels ? gt_labels[r] : -1;
+    int32_t *s_lab = reinterpret_cast<int32_t *>(s_gt + (size_t)B * gs);
+    uint16_t *s_bound = reinterpret_cast<uint16_t *>(s_lab + (size_t)B * gs);
+    const uint32_t mw = wave - SWEEP_SW;
+    {
+        // K images per wave and trip, dealt round-robin over the matcher waves; a trip's loads go out together, lane = GT
+        // row.  Same-box A/B at configs[1], K = 1 / 2 / 3 / 8: 39.4 / 39.4 / 39.7 / 39.85 us -- the trips are not what
+        // costs (B = 64 needs six of them at K = 1), the registers the wider forms hold are
+#ifndef ODBOX_SWEEP_STAGE_K
+#define ODBOX_SWEEP_STAGE_K 2
+#endif
+        constexpr uint32_t K = ODBOX_SWEEP_STAGE_K;
+        for (uint32_t b0 = mw; b0 < B; b0 += SWEEP_MW * K) {
+            float4 row[K];
+            int32_t lab[K];
+#pragma unroll
+            for (uint32_t k = 0; k < K; ++k) {
+                const uint32_t bk = b0 + k * SWEEP_MW;
+                const bool have = bk < B && lane < (uint32_t)G;
+                const size_t at = (size_t)bk * G + lane;
+                row[k] = have ? gt_boxes[at] : make_float4(-1.f, -1.f, -1.f, -1.f);
+                lab[k] = have && gt_labels ? gt_labels[at] : -1;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < K; ++k) {
+                const uint32_t bk = b0 + k * SWEEP_MW;
+                if (bk >= B) break;
+                const bool pad = fmaxf(fmaxf(row[k].x, row[k].y), fmaxf(row[k].z, row[k].w)) < 0.0f;      // bndbox.py:295
+                const uint64_t valid = __ballot(!pad && lane < (uint32_t)G);
+                const uint32_t bound = valid ? 64u - (uint32_t)__clzll((long long)valid) : 0u;
+                if (lane < min(bound, gs)) {
+                    s_gt[bk * gs + lane] = row[k];
+                    s_lab[bk * gs + lane] = lab[k];
+                }
+                if (lane == 0u) s_bound[bk] = (uint16_t)bound;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0u) atomicAdd(&s_staged, 1u);
         while (__hip_atomic_load(&s_staged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)SWEEP_MW) __builtin_amdgcn_s_sleep(2);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    auto gt_row = [&](uint32_t idx) -> float4 { return GT_LDS ? s_gt[idx] : gt_boxes[idx]; };
-    const uint32_t mw = wave - SWEEP_SW;
     const uint32_t j = lane >> 4, rr = lane & 15u;
     // lane = (piece j of the batch, row rr of the piece): the row, or rows = none
     auto locate = [&](uint32_t t, uint32_t &i, uint32_t &f0, uint32_t &f1) -> uint32_t {
@@ -659,21 +690,34 @@ __global__ __launch_bounds__(WAVE *(SWEEP_SW + SWEEP_MW)) void match_encode_swee
         if (R >= rows) continue;
         const uint32_t b = R / (uint32_t)N;
         const float a_area = (a.w - a.y) * (a.z - a.x);                       // bndbox.py:285
-        const uint32_t gbase = b * (uint32_t)G;
+        const uint32_t gbase = b * (uint32_t)G, sbase = b * gs;
+        const int bound = (int)s_bound[b];
         // ---- argmax_g IoU (anchors.py:253-256): padded rows count as -1, strict >, first maximum wins ----
         float best_iou = -INFINITY;
         int best = 0;
-        for (int g0 = 0; g0 < G; g0 += 4) {
+        auto four_rows = [&](int g0, int lim, auto load) {
             float4 gb[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) gb[k] = gt_row(gbase + (uint32_t)min(g0 + k, G - 1));
+            for (int k = 0; k < 4; ++k) gb[k] = load(min(g0 + k, lim - 1));
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float area = (gb[k].w - gb[k].y) * (gb[k].z - gb[k].x);                     // bndbox.py:286
                 const bool pad = fmaxf(fmaxf(gb[k].x, gb[k].y), fmaxf(gb[k].z, gb[k].w)) < 0.0f;  // bndbox.py:295
                 const float v = pad ? -1.0f : pair_iou(a, a_area, gb[k], area);
-                if (g0 + k < G && v > best_iou) { best_iou = v; best = g0 + k; }
+                if (g0 + k < lim && v > best_iou) { best_iou = v; best = g0 + k; }
             }
+        };
+        const int in_lds = min(bound, (int)gs) & ~3;             // whole groups of four from LDS, the rest from global memory
+        for (int g0 = 0; g0 < in_lds; g0 += 4) four_rows(g0, in_lds, [&](int g) { return s_gt[sbase + (uint32_t)g]; });
+        if (bound <= (int)gs) {
+            if (in_lds < bound) four_rows(in_lds, bound, [&](int g) { return s_gt[sbase + (uint32_t)g]; });
+        } else {
+            for (int g0 = in_lds; g0 < bound; g0 += 4) four_rows(g0, bound, [&](int g) { return gt_boxes[gbase + (uint32_t)g]; });
+        }
+        // rows bound .. G-1 are padding: in order they are one candidate of -1 at `bound` (later equals never win)
+        if (bound < G && -1.0f > best_iou) {
+            best_iou = -1.0f;
+            best = bound;
         }
         // ---- states, label (the second phase of match_tile, expression for expression) ----
         const bool positive = best_iou >= pos_thr;                            // anchors.py:267
@@ -683,7 +727,7 @@ __global__ __launch_bounds__(WAVE *(SWEEP_SW + SWEEP_MW)) void match_encode_swee
         ignore = ignore || (xc >= img_w) || (yc >= img_h);
         const int state = ignore ? -1 : (positive ? 1 : 0);
         int label = -1;
-        if (positive && !ignore && gt_labels) label = GT_LDS ? s_lab[gbase + best] : gt_labels[gbase + best];
+        if (positive && !ignore && gt_labels) label = best < (int)gs ? s_lab[sbase + (uint32_t)best] : gt_labels[gbase + (uint32_t)best];
         if (label < 0 || label >= C) label = -1;                              // tf.one_hot: zero row
         const uint32_t e0 = R * d;
         if (e0 >= f0) {                      // the row begins in this piece: its compact outputs and regression row are this lane's
@@ -691,7 +735,7 @@ __global__ __launch_bounds__(WAVE *(SWEEP_SW + SWEEP_MW)) void match_encode_swee
             if (out_state) out_state[R] = (int8_t)state;
             if (out_iou) out_iou[R] = best_iou;
             if (out_reg) {                                                    // anchors.py:286-297
-                const float4 g = gt_row(gbase + best);
+                const float4 g = best < (int)gs && best < bound ? s_gt[sbase + (uint32_t)best] : gt_boxes[gbase + (uint32_t)best];
                 const float aw = a.z - a.x, ah = a.w - a.y;
                 // one 20-byte row per lane, 4-byte aligned: two stores (dwordx3 + dwordx2) instead of five
                 struct __attribute__((packed, aligned(4))) Row5 { float v[5]; } r5;
@@ -1399,9 +1443,9 @@ bool recently_written(const void *ptr, uint64_t bytes)
 thread_local int g_last_plan = -1;      // odbox_match_encode_last_plan
 
 // does a streamed launch of odbox_match_encode take match_encode_sweep_kernel?
-bool sweep_applies(uint64_t label_bytes, int G, uint32_t d, bool labels_aligned16, bool gt_best)
+bool sweep_applies(uint64_t label_bytes, int B, int G, uint32_t d, bool labels_aligned16, bool gt_best)
 {
-    bool sweep = label_bytes > 0 && !gt_best && labels_aligned16 && G <= SWEEP_MAX_G &&
+    bool sweep = label_bytes > 0 && !gt_best && labels_aligned16 && G <= SWEEP_MAX_G && B <= SWEEP_MAX_B &&
                  (SWEEP_PIECE + d - 1u) / d + 1u <= (uint32_t)SWEEP_RPP &&
                  label_bytes / sizeof(float) <= 0xffffffffull - 4u * SWEEP_PIECE &&
                  label_bytes <= ((uint64_t)(train_tuning_env("ODBOX_SWEEP_MAX_MB") ? atoi(train_tuning_env("ODBOX_SWEEP_MAX_MB")) : ODBOX_SWEEP_MAX_MB) << 20);
@@ -1469,7 +1513,7 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
                                           (policy == ODBOX_POLICY_AUTO && label_bytes > ((uint64_t)ODBOX_STREAM_MB << 20)));
     // AUTO below the size rule, for the shapes the sweep serves (a label stream with a cheap match): around the caches
     // unless this very buffer was written a moment ago and is still in the Infinity Cache (recently_written)
-    if (policy == ODBOX_POLICY_AUTO && !stream_out && sweep_applies(label_bytes, G, d, aligned16(out_labels), out_gt_best != nullptr)) {
+    if (policy == ODBOX_POLICY_AUTO && !stream_out && sweep_applies(label_bytes, B, G, d, aligned16(out_labels), out_gt_best != nullptr)) {
         const uint64_t out_bytes = label_bytes + (out_regression ? (uint64_t)B * (uint64_t)N * 5u * sizeof(float) : 0u);
         stream_out = !recently_written(out_labels, out_bytes);
     }
@@ -1501,22 +1545,21 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
     };
     // streamed wide-row labels with a short GT list: the lockstep sweep (match_encode_sweep_kernel)
     const uint64_t total_floats = label_bytes / sizeof(float);
-    const bool sweep = stream_out && sweep_applies(label_bytes, G, d, aligned16(out_labels), keys != nullptr);
+    const bool sweep = stream_out && sweep_applies(label_bytes, B, G, d, aligned16(out_labels), keys != nullptr);
     if (sweep) {
         const uint32_t pieces = (uint32_t)((total_floats + SWEEP_PIECE - 1) / SWEEP_PIECE);
         uint32_t grid = 2u * (uint32_t)train_cu_count();
         if (const char *e = train_tuning_env("ODBOX_SWEEP_GRID")) grid = atoi(e) > 0 ? (uint32_t)atoi(e) : grid;
         if (grid > pieces) grid = pieces;
-        bool gt_lds = bg <= (uint32_t)SWEEP_LDS_ROWS && (uint64_t)B * (uint64_t)G <= (uint64_t)SWEEP_LDS_ROWS;
-        if (const char *e = train_tuning_env("ODBOX_SWEEP_GT_LDS")) gt_lds = gt_lds && atoi(e) != 0;
-        auto sweep_launch = [&](auto kernel, size_t lds) {
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(WAVE * (SWEEP_SW + SWEEP_MW)), lds, (hipStream_t)stream,
-                               (const float4 *)anchors, (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w, neg_thr,
-                               pos_thr, out_regression, out_labels, out_match_idx, out_state, out_max_iou,
-                               (uint32_t)((uint64_t)B * N), (uint32_t)total_floats, pieces, bg);
-        };
-        if (gt_lds) sweep_launch(match_encode_sweep_kernel<true>, (size_t)bg * 20);
-        else sweep_launch(match_encode_sweep_kernel<false>, 0);
+        // rows of every image kept in LDS: 20 bytes each, beside one 16-bit bound per image, in SWEEP_LDS_ROWS * 20 bytes
+        uint32_t gs = (uint32_t)SWEEP_LDS_ROWS * 20u > 2u * (uint32_t)B ? ((uint32_t)SWEEP_LDS_ROWS * 20u - 2u * (uint32_t)B) / (20u * (uint32_t)B) : 0u;
+        if (gs > (uint32_t)G) gs = (uint32_t)G;
+        if (const char *e = train_tuning_env("ODBOX_SWEEP_GT_LDS")) gs = atoi(e) != 0 ? gs : 0u;
+        const size_t lds = ((size_t)B * gs * 20 + (size_t)B * 2 + 15) & ~(size_t)15;
+        hipLaunchKernelGGL(match_encode_sweep_kernel, dim3(grid), dim3(WAVE * (SWEEP_SW + SWEEP_MW)), lds, (hipStream_t)stream,
+                           (const float4 *)anchors, (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w, neg_thr,
+                           pos_thr, out_regression, out_labels, out_match_idx, out_state, out_max_iou,
+                           (uint32_t)((uint64_t)B * N), (uint32_t)total_floats, pieces, (uint32_t)B, gs);
         g_last_plan = ODBOX_PLAN_SWEEP;
         return launch_status("match_encode_sweep");
     }
@@ -1545,7 +1588,7 @@ int odbox_match_encode_plan(int B, int N, int G, int C, int labels_aligned16, in
     const uint64_t label_bytes = (uint64_t)B * (uint64_t)N * d * sizeof(float);
     const int policy = g_output_policy.load(std::memory_order_relaxed);
     const bool stream_out = policy == ODBOX_POLICY_STREAM || (policy == ODBOX_POLICY_AUTO && label_bytes > ((uint64_t)ODBOX_STREAM_MB << 20));
-    const bool sweep = sweep_applies(label_bytes, G, d, labels_aligned16 != 0, want_gt_best != 0);
+    const bool sweep = sweep_applies(label_bytes, B, G, d, labels_aligned16 != 0, want_gt_best != 0);
     if (policy == ODBOX_POLICY_AUTO && !stream_out) return sweep ? ODBOX_PLAN_SWEEP : ODBOX_PLAN_TILES;      // a buffer not written a moment ago
     if (!stream_out) return ODBOX_PLAN_TILES;
     return sweep ? ODBOX_PLAN_SWEEP : ODBOX_PLAN_TILES_STREAM;

@@ -264,3 +264,30 @@ def test_auto_policy_follows_the_reuse_distance_of_the_buffer():
     for k in range(4):
         np.testing.assert_array_equal(cpu(bufs[k]), ref['labels'])
         np.testing.assert_array_equal(cpu(regs[k])[..., 4], ref['regression'][..., 4])
+
+
+def test_padding_layouts_and_rows_beyond_the_lds_share(stream_policy):
+    """The sweep's matcher never visits the padding behind an image's last valid row and keeps only the first
+    3 072 / B rows of every image in LDS.  Padded to 64 like the reference's batches, padding in FRONT of and BETWEEN
+    valid rows, all-padded images, and batches large enough that valid rows lie beyond the LDS share (B = 200: 15
+    rows per image; B = 3 100: none) must all give the oracle's argmax."""
+    rng = np.random.default_rng(4)
+    anchors = O.tile_anchors(O.base_anchors(32, (1, 2, .5)), 7, 5, 16)      # 315 anchors
+    for B, G, C in ((6, 64, 80), (200, 40, 70), (3100, 3, 68)):
+        gts = [workloads.gt_boxes(rng, 112, G, C) for _ in range(B)]
+        gt = np.stack([g[0] for g in gts])
+        lab = np.stack([g[1] for g in gts])
+        for b in range(B):
+            kind = b % 6
+            if kind == 0:
+                gt[b, rng.integers(1, G):] = -1                    # the usual case: a valid prefix, then padding
+            elif kind == 1 and G > 4:
+                gt[b, :G - 2] = -1                                 # padding first, two boxes at the very end
+            elif kind == 2 and G > 4:
+                gt[b, 1::2] = -1                                   # every other row padded
+            elif kind == 3:
+                gt[b] = -1                                         # nothing but padding
+            elif kind == 4 and G > 8:
+                gt[b, 2:G - 3] = -1                                # a hole
+            lab[b][gt[b, :, 2] < 0] = -1
+        check(anchors, (112, 80), gt, lab, C)

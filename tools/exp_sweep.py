@@ -12,7 +12,7 @@ cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 c = workloads.CONFIGS[cfg]
 anchors = bench.yolo_grid_anchors(416) if c['grid'] == 'yolo' else A.generate_anchors(A.AnchorsConfig(), c['S'])
-gt_np, lab_np = workloads.match_inputs(cfg, batch=B)
+gt_np, lab_np = workloads.match_inputs(cfg, batch=B, pad_to=int(os.environ['EXP_PAD_TO']) if os.environ.get('EXP_PAD_TO') else None)
 gt, lab = torch.as_tensor(gt_np).to(dev), torch.as_tensor(lab_np).to(dev)
 N, G, C, S = anchors.shape[0], gt.shape[1], c['C'], c['S']
 per_set = B * N * (C + 6) * 4
