@@ -434,9 +434,17 @@ __global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE_ENC) void match_e
     // ... and both orders run back to front: the coarse pyramid levels at the end of the anchor array
     // have the longest work lists (every GT row reaches into their tiles), so they go first and the
     // launch ends on cheap tiles (config 4: 413 -> 400 us, configs 1 / 3: -1.5 % / -1 %)
-    const uint32_t blk = gridDim.x - 1u - (remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x);
-    const uint32_t b = blk / tiles_per_image;
-    const uint32_t n0 = (blk - b * tiles_per_image) * TILE;
+    const uint32_t blk = gridDim.x - 1u - (remap && !GTBEST ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x);
+    // GTBEST: tile-major order (all images' last tile, then all images' tile before it, ...), so that the tiles of one
+    // image run one after the other rather than all at once: a tile then finds the per-GT keys its predecessors posted
+    // and most of its (wave, row) pairs fail the "can I reach the best so far" test instead of reducing over the
+    // wavefront (dense crowd with the output on: 700 us with all tiles of an image in flight together).  XCD = block
+    // mod 8 = image mod 8: balanced, and an image's GT rows and keys stay in one L2.
+    const uint32_t n_img = gridDim.x / tiles_per_image;
+    const uint32_t b = GTBEST ? blk % n_img : blk / tiles_per_image;
+    // (GTBEST: `remap` carries a multiplier coprime to tiles_per_image -- the tiles of an image in a scattered order: a
+    // sweep through the anchor grid approaches every GT box step by step, and every step raises its best)
+    const uint32_t n0 = (GTBEST ? (uint32_t)(((uint64_t)(blk / n_img) * remap) % tiles_per_image) : blk - b * tiles_per_image) * TILE;
     const uint32_t n = n0 + tid;
     const bool live = n < (uint32_t)N;
     const uint32_t tile_n = min((uint32_t)TILE, (uint32_t)N - n0);
@@ -1572,8 +1580,19 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
     // per-GT best anchor: the records double as the 64-bit keys while the matcher runs
     hipLaunchKernelGGL(gt_best_init_kernel, dim3((bg + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, keys, bg);
     if (int rc = launch_status("gt_best_init")) return rc;
-    if (stream_out) launch(match_encode_kernel<true, true>);
-    else launch(match_encode_kernel<false, true>);
+    // tile order of the per-GT variant: multiples of a number near 0.618 * tiles that is coprime to it (see the kernel)
+    uint32_t mult = (uint32_t)((double)tiles * 0.6180339887) | 1u;
+    auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
+    while (gcd(mult, tiles) != 1) mult += 2;
+    if (train_tuning_env("ODBOX_GTBEST_LINEAR")) mult = 1;
+    auto launch_best = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(tile), pad_lds, (hipStream_t)stream,
+                           (const float4 *)anchors, (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w,
+                           neg_thr, pos_thr, out_regression, out_labels, out_match_idx, out_state, out_max_iou,
+                           keys, (uint32_t)tiles, mult);
+    };
+    if (stream_out) launch_best(match_encode_kernel<true, true>);
+    else launch_best(match_encode_kernel<false, true>);
     if (int rc = launch_status("match_encode")) return rc;
     hipLaunchKernelGGL(gt_best_finalize_kernel, dim3((bg + 255u) / 256u), dim3(256), 0, (hipStream_t)stream,
                        (const float4 *)anchors, (const float4 *)gt_boxes, N, G, keys, bg);
