@@ -59,7 +59,7 @@ int odbox_set_output_policy(int policy);
  * policy (no counterpart in the reference; for tests, benchmarks and logs -- the results are the same
  * bits on every plan).  TILES: one block per 256-anchor tile, stores through the caches.  TILES_STREAM:
  * 64-anchor tiles, nontemporal stores.  SWEEP: streamed outputs with wide label rows (C + 1 >= 69), at
- * most 64 GT rows, 16-byte aligned labels, no per-GT output and at most 768 MB of labels: the label tensor
+ * most 64 GT rows, B <= 8192, 16-byte aligned labels, no per-GT output and at most 768 MB of labels: the label tensor
  * is written as one chip-wide lockstep sweep of 4 KB pieces by dedicated store waves while other waves
  * of the same blocks match and patch (the fastest order into cold HBM).  Under AUTO the answer is the one
  * for a buffer that no recent call wrote.  Returns ODBOX_EINVAL on a bad shape.

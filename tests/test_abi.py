@@ -218,6 +218,7 @@ def test_every_entry_rejects_bad_arguments_without_touching_the_gpu(lib):
     assert [lib.odbox_match_encode_plan(64, 10647, 20, 80, a, g) for a, g in ((1, 0), (0, 0), (1, 1))] == [2, 1, 1]
     assert lib.odbox_match_encode_plan(64, 10647, 65, 80, 1, 0) == 1 and lib.odbox_match_encode_plan(64, 10647, 20, 67, 1, 0) == 1
     assert lib.odbox_match_encode_plan(128, 49104, 500, 1, 1, 0) == 1
+    assert lib.odbox_match_encode_plan(8192, 300, 3, 80, 1, 0) == 2 and lib.odbox_match_encode_plan(8193, 300, 3, 80, 1, 0) == 1
     assert lib.odbox_set_output_policy(0) == 2
     assert lib.odbox_match_encode_plan(0, 1, 1, 1, 1, 0) == -1 and b'odbox_match_encode_plan' in lib.odbox_last_error()
     # empty problems are successes, decided before any pointer is looked at
