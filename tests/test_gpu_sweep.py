@@ -88,7 +88,8 @@ def random_case(rng, B, N, G, C, S=256, pads=2):
 # rows of C + 1 = 69 .. 201 floats; anchor counts that put row and image boundaries anywhere inside the 4 KB
 # pieces; totals that are not a multiple of 4 floats (scalar tail); fewer pieces than blocks; G = 1 .. 64
 @pytest.mark.parametrize('B,N,G,C', [(1, 1, 1, 68), (1, 3, 2, 80), (2, 255, 3, 80), (3, 257, 7, 90), (2, 1000, 20, 80),
-                                     (1, 513, 64, 69), (5, 4099, 33, 100), (2, 7001, 20, 200), (7, 1237, 5, 71)])
+                                     (1, 513, 64, 69), (5, 4099, 33, 100), (2, 7001, 20, 200), (7, 1237, 5, 71),
+                                     (8192, 37, 2, 70)])
 def test_random_shapes_bit_exact(stream_policy, B, N, G, C):
     rng = np.random.default_rng(B * 1000 + N + G + C)
     anchors, gt, lab = random_case(rng, B, N, G, C)
