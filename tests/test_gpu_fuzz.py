@@ -154,3 +154,79 @@ def test_decode_nms_random_shapes(seed):
     np.testing.assert_array_equal(l, ref[2])
     np.testing.assert_array_equal(s, ref[1])
     np.testing.assert_allclose(b, ref[0], rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize('seed', range(64))
+def test_sweep_random_shapes_and_placements(seed):
+    """The lockstep sweep (ODBOX_POLICY_STREAM; wide label rows, short GT lists, labels on a 16-byte boundary): random
+    batch sizes up to 300 (valid rows beyond the LDS share), anchor counts that put image and row boundaries anywhere in
+    the 4 KB pieces, padding before / between / behind valid rows, optional outputs, NaN-filled buffers with guard
+    bands, against the C oracle."""
+    rng = np.random.default_rng(9000 + seed)
+    B = int(rng.choice([1, 2, 3, 5, 17, 64, 150, 300]))
+    N = int(rng.choice([1, 2, 13, 63, 64, 65, 255, 257, 300, 777, 1025])) if B > 17 else int(rng.choice([1, 12, 13, 257, 1025, 4097, 9999]))
+    G = int(rng.choice([1, 2, 3, 7, 20, 33, 64]))
+    C = int(rng.choice([68, 69, 79, 80, 81, 90, 127, 255]))
+    S = float(rng.choice([64, 100, 416]))
+    cx, cy = rng.uniform(0, S, N), rng.uniform(0, S, N)
+    w, h = rng.uniform(2, S / 2, N), rng.uniform(2, S / 2, N)
+    anchors = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).astype(np.float32)
+    gx, gy = rng.uniform(0, S, (B, G)), rng.uniform(0, S, (B, G))
+    gw, gh = rng.uniform(1, S / 2, (B, G)), rng.uniform(1, S / 2, (B, G))
+    gt = np.stack([gx - gw / 2, gy - gh / 2, gx + gw / 2, gy + gh / 2], -1).astype(np.float32)
+    lab = rng.integers(-1, C + 2, (B, G)).astype(np.int32)
+    for b in range(B):
+        kind = rng.random()
+        if kind < 0.5:
+            gt[b, int(rng.integers(0, G + 1)):] = -1                 # valid prefix
+        elif kind < 0.7:
+            gt[b, rng.random(G) < 0.5] = -1                           # holes anywhere
+        elif kind < 0.8:
+            gt[b, :int(rng.integers(0, G + 1))] = -1                  # padding in front
+        if G >= 2 and rng.random() < 0.4:
+            gt[b, 1] = gt[b, 0]
+        if rng.random() < 0.4:
+            gt[b, 0] = anchors[int(rng.integers(0, N))]
+        lab[b][gt[b, :, 2] < 0] = -1
+    hw = (S, float(rng.choice([S, S - 16])))
+    ref = c_oracle.match_encode(anchors, hw, gt, lab, C, threads=8)
+    lib = _lib.load()
+    dev = torch.device('cuda')
+    want_reg, want_compact = rng.random() < 0.8, rng.random() < 0.5
+    off_r, off_l = int(rng.integers(0, 40)), 4 * int(rng.integers(0, 10))
+    guard = 64
+    breg = torch.full((guard + off_r + B * N * 5 + guard,), float('nan'), device=dev)
+    blab = torch.full((guard + off_l + B * N * (C + 1) + guard,), float('nan'), device=dev)
+    reg = breg[guard + off_r: guard + off_r + B * N * 5]
+    labels = blab[guard + off_l: guard + off_l + B * N * (C + 1)]
+    idx = torch.full((B, N), -7, dtype=torch.int32, device=dev)
+    state = torch.full((B, N), -7, dtype=torch.int8, device=dev)
+    iou = torch.full((B, N), float('nan'), device=dev)
+    a, g, l = (torch.as_tensor(x).to(dev) for x in (anchors, gt, lab))
+    p = lambda t, on=True: ctypes.c_void_p(t.data_ptr()) if on else None      # noqa: E731
+    prev = lib.odbox_set_output_policy(2)
+    try:
+        rc = lib.odbox_match_encode(p(a), p(g), p(l), B, N, G, C, hw[0], hw[1], 0.4, 0.5, p(reg, want_reg), p(labels),
+                                    p(idx, want_compact), p(state, want_compact), p(iou, want_compact), None, _lib.stream_ptr())
+        took = lib.odbox_match_encode_last_plan()
+    finally:
+        lib.odbox_set_output_policy(prev)
+    assert rc == 0, lib.odbox_last_error()
+    assert took == 2, 'not the sweep'
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(labels.view(B, N, C + 1).cpu().numpy(), ref['labels'])
+    if want_reg:
+        got = reg.view(B, N, 5).cpu().numpy()
+        np.testing.assert_array_equal(got[..., 4], ref['regression'][..., 4])
+        with np.errstate(invalid='ignore'):
+            np.testing.assert_allclose(got[..., :4], ref['regression'][..., :4], rtol=1e-5, atol=0)
+    else:
+        assert torch.isnan(reg).all()
+    if want_compact:
+        np.testing.assert_array_equal(idx.cpu().numpy(), ref['match_idx'])
+        np.testing.assert_array_equal(state.cpu().numpy(), ref['state'])
+        np.testing.assert_array_equal(iou.cpu().numpy(), ref['max_iou'])
+    else:
+        assert (idx == -7).all() and (state == -7).all()
+    for buf, off, n in ((breg, off_r, B * N * 5), (blab, off_l, B * N * (C + 1))):
+        assert torch.isnan(buf[:guard + off]).all() and torch.isnan(buf[guard + off + n:]).all()
