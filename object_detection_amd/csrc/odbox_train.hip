@@ -594,7 +594,7 @@ __global__ __launch_bounds__(WAVE *(SWEEP_SW + SWEEP_MW)) void match_encode_swee
     const float4 *__restrict__ anchors, const float4 *__restrict__ gt_boxes, const int32_t *__restrict__ gt_labels, int N,
     int G, int C, float img_h, float img_w, float neg_thr, float pos_thr, float *__restrict__ out_reg, float *out_lab,
     int32_t *__restrict__ out_idx, int8_t *__restrict__ out_state, float *__restrict__ out_iou, uint32_t rows,
-    uint32_t total, uint32_t pieces, uint32_t B, uint32_t gs)
+    uint32_t total, uint32_t pieces, uint32_t B, uint32_t gs, uint32_t xcd_runs)
 {
     typedef float v4f_ __attribute__((ext_vector_type(4)));
     extern __shared__ float4 s_gt[];                    // [B * gs] boxes, [B * gs] labels, [B] bounds
@@ -605,8 +605,13 @@ __global__ __launch_bounds__(WAVE *(SWEEP_SW + SWEEP_MW)) void match_encode_swee
     if (tid < SWEEP_SW) s_done[tid] = 0u;
     if (tid == SWEEP_SW) s_staged = 0u;
     __syncthreads();
-    if (blockIdx.x >= pieces) return;
-    const uint32_t mine = (pieces - blockIdx.x + gridDim.x - 1u) / gridDim.x;      // pieces of this block: blockIdx.x + i * gridDim.x
+    // xcd_runs: XCD x (blocks x, x + 8, ...) owns a contiguous eighth of every step's window, so neighbouring pieces
+    // share an L2 -- the regression rows of a piece end inside cache lines whose other half the next piece's owner
+    // writes, and two L2s each wrote their half back.  Same-box A/B: configs[0] 23.5 -> 22.8 us, configs[1] 39.55 ->
+    // 38.7 us, 64-row padded GT 40.2 -> 39.4 us; 517 MB of labels 90.1 -> 91.2 us (hence the host's size rule)
+    const uint32_t slot = xcd_runs ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    if (slot >= pieces) return;
+    const uint32_t mine = (pieces - slot + gridDim.x - 1u) / gridDim.x;      // pieces of this block: slot + i * gridDim.x
     if (wave < SWEEP_SW) {
         __builtin_amdgcn_s_setprio(3);
         const v4f_ z = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -619,7 +624,7 @@ __global__ __launch_bounds__(WAVE *(SWEEP_SW + SWEEP_MW)) void match_encode_swee
         for (uint32_t i = 0; i < mine; ++i) {
 #pragma unroll
             for (uint32_t k = 0; k < PER; ++k) {
-                const uint32_t f = (blockIdx.x + i * gridDim.x) * SWEEP_PIECE + off + k * 256u;
+                const uint32_t f = (slot + i * gridDim.x) * SWEEP_PIECE + off + k * 256u;
                 if (f + 3u < total) {
                     __builtin_nontemporal_store(z, reinterpret_cast<v4f_ *>(out_lab + f));
                 } else {
@@ -682,7 +687,7 @@ __global__ __launch_bounds__(WAVE *(SWEEP_SW + SWEEP_MW)) void match_encode_swee
     auto locate = [&](uint32_t t, uint32_t &i, uint32_t &f0, uint32_t &f1) -> uint32_t {
         i = t * 4u + j;
         if (i >= mine) return rows;
-        f0 = (blockIdx.x + i * gridDim.x) * SWEEP_PIECE;
+        f0 = (slot + i * gridDim.x) * SWEEP_PIECE;
         f1 = min(f0 + (uint32_t)SWEEP_PIECE, total);
         const uint32_t R = f0 / d + rr;                           // the piece's first row begins at or before f0
         return (R < rows && R * d < f1) ? R : rows;
@@ -1564,10 +1569,12 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
         if (gs > (uint32_t)G) gs = (uint32_t)G;
         if (const char *e = train_tuning_env("ODBOX_SWEEP_GT_LDS")) gs = atoi(e) != 0 ? gs : 0u;
         const size_t lds = ((size_t)B * gs * 20 + (size_t)B * 2 + 15) & ~(size_t)15;
+        uint32_t xcd_runs = (grid & 7u) == 0u && label_bytes <= (384ull << 20) ? 1u : 0u;      // see the kernel
+        if (const char *e = train_tuning_env("ODBOX_SWEEP_XCD_RUNS")) xcd_runs = xcd_runs && atoi(e) != 0;
         hipLaunchKernelGGL(match_encode_sweep_kernel, dim3(grid), dim3(WAVE * (SWEEP_SW + SWEEP_MW)), lds, (hipStream_t)stream,
                            (const float4 *)anchors, (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w, neg_thr,
                            pos_thr, out_regression, out_labels, out_match_idx, out_state, out_max_iou,
-                           (uint32_t)((uint64_t)B * N), (uint32_t)total_floats, pieces, (uint32_t)B, gs);
+                           (uint32_t)((uint64_t)B * N), (uint32_t)total_floats, pieces, (uint32_t)B, gs, xcd_runs);
         g_last_plan = ODBOX_PLAN_SWEEP;
         return launch_status("match_encode_sweep");
     }
