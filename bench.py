@@ -233,13 +233,13 @@ def cpu_baseline_nms(anchors_np, reg_np, sc_np, S, budget_s=4.0):
     return out
 
 
-def match_encode_case(lib, dev, stream, cfg, B, anchors, seed, sets):
+def match_encode_case(lib, dev, stream, cfg, B, anchors, seed, sets, pad_to=None):
     """Device buffers + a step(i) closure of odbox_match_encode on BASELINE config `cfg` with batch B,
-    writing output set i % sets."""
+    writing output set i % sets.  pad_to: GT rows padded with -1 up to that many (detection.py:246-266 pads to 64)."""
     c = workloads.CONFIGS[cfg]
     S, C = c['S'], c['C']
     N = anchors.shape[0]
-    gt_np, lab_np = workloads.match_inputs(cfg, batch=B, seed=seed)
+    gt_np, lab_np = workloads.match_inputs(cfg, batch=B, seed=seed, pad_to=pad_to)
     gt = torch.as_tensor(gt_np).to(dev)
     lab = torch.as_tensor(lab_np).to(dev)
     G = gt.shape[1]
@@ -355,6 +355,9 @@ def main():
         ksteps = max(10, min(args.steps, 30))
         retina512 = A.generate_anchors(A.AnchorsConfig(), 512)
         for key, cfg, Bc, anch, sets, label in (
+                ('match_encode_cfg1_padded64', 2, 64, anchors, OUTPUT_SETS,
+                 'the headline batch as the reference feeds it: GT rows padded with -1 to MAX_ITEMS_IN_IMAGE = 64 '
+                 '(detection.py:246-266), 20 of them boxes; %d output sets in rotation' % OUTPUT_SETS),
                 ('match_encode_cfg0', 1, 8, retina512, 8,
                  'configs[0]: EfficientDet-D0 512x512, 49 104 anchors, 80 classes, 20 GT, batch 8; 8 output sets in rotation'),
                 ('match_encode_cfg2', 3, 32, None, 1,
@@ -363,7 +366,8 @@ def main():
                  'configs[3]: dense crowd, 500 GT boxes/img vs 49 104 anchors, 1 class, batch 128')):
             if anch is None:
                 anch = A.generate_anchors(A.AnchorsConfig(), workloads.CONFIGS[cfg]['S'])
-            stepc, wc = match_encode_case(lib, dev, stream, cfg, Bc, anch, 1000 + cfg + 7919 * rank, sets)
+            stepc, wc = match_encode_case(lib, dev, stream, cfg, Bc, anch, 1000 + cfg + 7919 * rank, sets,
+                                          pad_to=64 if key.endswith('padded64') else None)
             lib.odbox_set_output_policy(2 if sets > 2 else 0)           # rotating (cold) outputs: written around the caches
             k_cfg = match_encode_kernel_name(lib, Bc, wc['N'], wc['G'], wc['C'])
             wl, el = timed(stepc, ksteps, 3, world)
