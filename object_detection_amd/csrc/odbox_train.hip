@@ -1418,7 +1418,7 @@ int train_cu_count()
 // does NOT see: a training step between two calls streams gigabytes through the cache, and at 6 TB/s 256 MB last 40 us.
 constexpr uint64_t MALL_BYTES = 256ull << 20;
 constexpr int RECENT_OUTS = 16;
-constexpr std::chrono::microseconds RECENT_WINDOW{2000};
+constexpr std::chrono::microseconds RECENT_WINDOW{5000};
 struct RecentOut {
     const void *ptr;
     uint64_t bytes;
