@@ -173,7 +173,7 @@ def per_step_median(fn, groups=10, per_group=10):
 
 
 PLAN_KERNELS = {0: 'match_encode_kernel<false, false>', 1: 'match_encode_kernel<true, false>',
-                2: 'match_encode_sweep_kernel<true>'}
+                2: 'match_encode_sweep_kernel'}
 
 
 def match_encode_kernel_name(lib, B, N, G, C):

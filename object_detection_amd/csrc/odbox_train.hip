@@ -553,7 +553,8 @@ __global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE_ENC) void match_e
 //                          label elements (state, the one 1.0) patched by the lane of the piece each
 //                          element lies IN, once the store waves say that piece's zeros are out -- a row
 //                          that straddles two pieces is matched twice, by the two blocks that own them.
-// Taken by odbox_match_encode for streamed outputs (ODBOX_POLICY_STREAM, or AUTO beyond ODBOX_STREAM_MB)
+// Taken by odbox_match_encode for streamed outputs (ODBOX_POLICY_STREAM; AUTO beyond ODBOX_STREAM_MB or for a buffer
+// that is not still in the Infinity Cache, see recently_written)
 // with wide label rows (C + 1 >= 69: at most 16 rows per piece), G <= 64, 16-byte aligned labels of at most
 // ODBOX_SWEEP_MAX_MB and no per-GT output; everything else stays with match_encode_kernel.
 // ------------------------------------------------------------------------------------------
