@@ -292,3 +292,48 @@ def test_padding_layouts_and_rows_beyond_the_lds_share(stream_policy):
                 gt[b, 2:G - 3] = -1                                # a hole
             lab[b][gt[b, :, 2] < 0] = -1
         check(anchors, (112, 80), gt, lab, C)
+
+
+def test_sweep_replays_from_a_hip_graph(stream_policy):
+    """The sweep allocates nothing and reads everything it decides on from device memory (the per-image bounds are
+    recomputed by every launch): captured once, replayed on batches with other boxes and other amounts of padding."""
+    lib = _lib.load()
+    dev = torch.device('cuda')
+    anchors_np = O.generate_anchors(256)
+    N, C, B, G = anchors_np.shape[0], 80, 5, 64
+    anchors = torch.as_tensor(anchors_np).to(dev)
+
+    def inputs(seed, valid):
+        r = np.random.default_rng(seed)
+        gts = [workloads.gt_boxes(r, 256, valid, C, pad_to=G) for _ in range(B)]
+        return np.stack([g[0] for g in gts]), np.stack([g[1] for g in gts])
+
+    gt_np, lab_np = inputs(1, 20)
+    gt, lab = torch.as_tensor(gt_np).to(dev), torch.as_tensor(lab_np).to(dev)
+    out_reg = torch.empty((B, N, 5), device=dev)
+    out_lab = torch.empty((B, N, C + 1), device=dev)
+    idx = torch.empty((B, N), dtype=torch.int32, device=dev)
+
+    def enqueue():
+        rc = lib.odbox_match_encode(anchors.data_ptr(), gt.data_ptr(), lab.data_ptr(), B, N, G, C, 256.0, 256.0, 0.4, 0.5,
+                                    out_reg.data_ptr(), out_lab.data_ptr(), idx.data_ptr(), None, None, None, _lib.stream_ptr())
+        assert rc == 0, lib.odbox_last_error()
+        assert A.match_encode_last_plan() == 'sweep'
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        enqueue()
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        enqueue()
+    for seed, valid in ((2, 3), (3, 64), (4, 41)):
+        g2, l2 = inputs(seed, valid)
+        gt.copy_(torch.as_tensor(g2)), lab.copy_(torch.as_tensor(l2))
+        out_lab.fill_(7.0), out_reg.fill_(7.0), idx.fill_(-7)
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = c_oracle.match_encode(anchors_np, (256, 256), g2, l2, C, threads=4)
+        np.testing.assert_array_equal(cpu(out_lab), ref['labels'])
+        np.testing.assert_array_equal(cpu(idx), ref['match_idx'])
+        np.testing.assert_array_equal(cpu(out_reg)[..., 4], ref['regression'][..., 4])
