@@ -48,7 +48,8 @@ const char *odbox_last_error(void);
  * 512 MB go around the caches; label-stream shapes (those the lockstep sweep serves, see
  * odbox_match_encode_plan) go around them too UNLESS this very buffer was written by a call of the last 5 ms
  * and the bytes the library has written since fit the cache; everything else goes through.  CACHE / STREAM
- * force one or the other.  Process-wide; returns the previous policy, or ODBOX_EINVAL.  Results are
+ * force one or the other -- except that label rows narrower than 64 floats (C < 63) always go through the
+ * caches: streamed, their tiles are too small to be worth a block each.  Process-wide; returns the previous policy, or ODBOX_EINVAL.  Results are
  * bit-identical under every policy. */
 #define ODBOX_POLICY_AUTO   0
 #define ODBOX_POLICY_CACHE  1

@@ -573,6 +573,7 @@ constexpr int SWEEP_MW = ODBOX_SWEEP_MW;        // matcher waves
 constexpr int SWEEP_RPP = 16;                   // anchor rows that can touch one piece
 constexpr int SWEEP_VMK = ODBOX_SWEEP_VMK;      // stores a store wave keeps in flight behind its progress counter
 constexpr int SWEEP_MAX_G = 64;
+constexpr int STREAM_MIN_ROW = 64;              // label floats per anchor from which odbox_match_encode streams at all (see there)
 #ifndef ODBOX_SWEEP_MAX_MB
 // label bytes up to which the sweep is taken.  Same-box A/B against the 64-anchor tiles on cold buffers (tools/exp_sweep.py):
 // 135 MB (configs[0]) 27.2 -> 23.4 us, 234 MB (configs[1]) 43.2 -> 39.1 us, 270 MB 49.5 -> 43.5 us, 540 MB 90-93 -> 87-88 us,
@@ -1525,6 +1526,11 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
     const int policy = g_output_policy.load(std::memory_order_relaxed);
     bool stream_out = label_bytes > 0 && (policy == ODBOX_POLICY_STREAM ||
                                           (policy == ODBOX_POLICY_AUTO && label_bytes > ((uint64_t)ODBOX_STREAM_MB << 20)));
+    // Narrow label rows always go through the caches: the streaming variant's 64-anchor tiles shrink with the row (C = 20:
+    // 5 KB per block) and its launch becomes block- and match-bound -- same-box, 229 MB of labels, cold / in place:
+    // C = 20 111 / 111 us around the caches against 63 / 51 us through them, C = 40 62 / 62 against 55 / 36 us
+    // (tools/exp_policy_narrow.py); from C + 1 = 64 floats per row the stream wins (C = 80: 43 against 49.5 us cold)
+    stream_out = stream_out && d >= (uint32_t)STREAM_MIN_ROW;
     // AUTO below the size rule, for the shapes the sweep serves (a label stream with a cheap match): around the caches
     // unless this very buffer was written a moment ago and is still in the Infinity Cache (recently_written)
     if (policy == ODBOX_POLICY_AUTO && !stream_out && sweep_applies(label_bytes, B, G, d, aligned16(out_labels), out_gt_best != nullptr)) {
@@ -1614,7 +1620,8 @@ int odbox_match_encode_plan(int B, int N, int G, int C, int labels_aligned16, in
     const uint32_t d = (uint32_t)C + 1u;
     const uint64_t label_bytes = (uint64_t)B * (uint64_t)N * d * sizeof(float);
     const int policy = g_output_policy.load(std::memory_order_relaxed);
-    const bool stream_out = policy == ODBOX_POLICY_STREAM || (policy == ODBOX_POLICY_AUTO && label_bytes > ((uint64_t)ODBOX_STREAM_MB << 20));
+    const bool stream_out = (policy == ODBOX_POLICY_STREAM || (policy == ODBOX_POLICY_AUTO && label_bytes > ((uint64_t)ODBOX_STREAM_MB << 20))) &&
+                            d >= (uint32_t)STREAM_MIN_ROW;
     const bool sweep = sweep_applies(label_bytes, B, G, d, labels_aligned16 != 0, want_gt_best != 0);
     if (policy == ODBOX_POLICY_AUTO && !stream_out) return sweep ? ODBOX_PLAN_SWEEP : ODBOX_PLAN_TILES;      // a buffer not written a moment ago
     if (!stream_out) return ODBOX_PLAN_TILES;

@@ -217,7 +217,8 @@ def test_every_entry_rejects_bad_arguments_without_touching_the_gpu(lib):
     assert lib.odbox_set_output_policy(2) == 0
     assert [lib.odbox_match_encode_plan(64, 10647, 20, 80, a, g) for a, g in ((1, 0), (0, 0), (1, 1))] == [2, 1, 1]
     assert lib.odbox_match_encode_plan(64, 10647, 65, 80, 1, 0) == 1 and lib.odbox_match_encode_plan(64, 10647, 20, 67, 1, 0) == 1
-    assert lib.odbox_match_encode_plan(128, 49104, 500, 1, 1, 0) == 1
+    assert lib.odbox_match_encode_plan(128, 49104, 500, 1, 1, 0) == 0              # narrow label rows never stream
+    assert lib.odbox_match_encode_plan(600, 10647, 20, 20, 1, 0) == 0 and lib.odbox_match_encode_plan(600, 10647, 20, 63, 1, 0) == 1
     assert lib.odbox_match_encode_plan(8192, 300, 3, 80, 1, 0) == 2 and lib.odbox_match_encode_plan(8193, 300, 3, 80, 1, 0) == 1
     assert lib.odbox_set_output_policy(0) == 2
     assert lib.odbox_match_encode_plan(0, 1, 1, 1, 1, 0) == -1 and b'odbox_match_encode_plan' in lib.odbox_last_error()
