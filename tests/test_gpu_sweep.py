@@ -250,16 +250,25 @@ def test_auto_policy_follows_the_reuse_distance_of_the_buffer():
         assert rc == 0, lib.odbox_last_error()
         return A.match_encode_last_plan()
 
+    def soon(ks, want, tries=4):
+        # the rule has a 5 ms clock in it: a host that stalls between two calls only ever turns 'tiles' into 'sweep',
+        # so a 'tiles' expectation gets a few tries and a 'sweep' expectation none
+        for _ in range(tries):
+            if [call(k) for k in ks] == [want] * len(ks):
+                return True
+        return False
+
     assert call(0) == 'sweep'                                           # never seen
-    assert [call(0) for _ in range(3)] == ['tiles'] * 3                 # rewritten in place: still in the cache
+    assert soon((0, 0, 0), 'tiles')                                     # rewritten in place: still in the cache
     assert call(1) == 'sweep'
-    assert [call(k) for k in (0, 1, 0, 1)] == ['tiles'] * 4             # two buffers, 2 x 88 MB: both stay resident
+    call(0)
+    assert soon((1, 0, 1, 0), 'tiles')                                  # two buffers, 2 x 88 MB: both stay resident
     assert [call(k) for k in (2, 3)] == ['sweep'] * 2
-    assert [call(k) for k in (0, 1, 2, 3)] == ['sweep'] * 4             # four in rotation: 352 MB between two writes of one
+    assert [call(k) for k in (1, 0, 2, 3)] == ['sweep'] * 4             # four in rotation, oldest first: 352 MB between two writes of one
     torch.cuda.synchronize()
     time.sleep(0.02)
     assert call(3) == 'sweep'                                           # written last, but 20 ms ago
-    assert call(3) == 'tiles'
+    assert soon((3,), 'tiles')
     torch.cuda.synchronize()
     ref = c_oracle.match_encode(anchors, (416, 416), gt, lab, C, threads=8)
     for k in range(4):
