@@ -45,7 +45,7 @@ const char *odbox_last_error(void);
  * GPU's memory system).  Through the caches is right when the stores land in lines the 256 MB Infinity Cache
  * still holds (one buffer rewritten call after call) or when the consumer reads the targets next; around
  * them (nontemporal stores) when the buffer is fresh or large.  AUTO (default) decides per call: labels beyond
- * 512 MB go around the caches; label-stream shapes (those the lockstep sweep serves, see
+ * 512 MB go around the caches (GT lists of at most 80 rows); label-stream shapes (those the lockstep sweep serves, see
  * odbox_match_encode_plan) go around them too UNLESS this very buffer was written by a call of the last 5 ms
  * and the bytes the library has written since fit the cache; everything else goes through.  CACHE / STREAM
  * force one or the other -- except that label rows narrower than 64 floats (C < 63) always go through the

@@ -573,6 +573,7 @@ constexpr int SWEEP_MW = ODBOX_SWEEP_MW;        // matcher waves
 constexpr int SWEEP_RPP = 16;                   // anchor rows that can touch one piece
 constexpr int SWEEP_VMK = ODBOX_SWEEP_VMK;      // stores a store wave keeps in flight behind its progress counter
 constexpr int SWEEP_MAX_G = 64;
+constexpr int STREAM_AUTO_MAX_G = 80;           // GT rows up to which ODBOX_POLICY_AUTO streams large label tensors
 constexpr int STREAM_MIN_ROW = 64;              // label floats per anchor from which odbox_match_encode streams at all (see there)
 #ifndef ODBOX_SWEEP_MAX_MB
 // label bytes up to which the sweep is taken.  Same-box A/B against the 64-anchor tiles on cold buffers (tools/exp_sweep.py):
@@ -1524,8 +1525,12 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
     // through the caches even when they would fit -- configs[1] into cold buffers: 50.2 us through the
     // caches, 43.6 us around them; rewriting ONE buffer in place: 33.2 us against 43.6 us.
     const int policy = g_output_policy.load(std::memory_order_relaxed);
+    // (AUTO's size rule stops at 80 GT rows: the streaming variant's one-wave blocks pay for long lists -- 1.03 GB of labels,
+    // G = 20 / 65 / 100 / 200 real boxes: 176 / 217 / 255 / 373 us around the caches against 210 / 231 / 246 / 291 us through
+    // them, tools/exp_policy_longgt.py 300)
     bool stream_out = label_bytes > 0 && (policy == ODBOX_POLICY_STREAM ||
-                                          (policy == ODBOX_POLICY_AUTO && label_bytes > ((uint64_t)ODBOX_STREAM_MB << 20)));
+                                          (policy == ODBOX_POLICY_AUTO && label_bytes > ((uint64_t)ODBOX_STREAM_MB << 20) &&
+                                           G <= STREAM_AUTO_MAX_G));
     // Narrow label rows always go through the caches: the streaming variant's 64-anchor tiles shrink with the row (C = 20:
     // 5 KB per block) and its launch becomes block- and match-bound -- same-box, 229 MB of labels, cold / in place:
     // C = 20 111 / 111 us around the caches against 63 / 51 us through them, C = 40 62 / 62 against 55 / 36 us
@@ -1620,7 +1625,8 @@ int odbox_match_encode_plan(int B, int N, int G, int C, int labels_aligned16, in
     const uint32_t d = (uint32_t)C + 1u;
     const uint64_t label_bytes = (uint64_t)B * (uint64_t)N * d * sizeof(float);
     const int policy = g_output_policy.load(std::memory_order_relaxed);
-    const bool stream_out = (policy == ODBOX_POLICY_STREAM || (policy == ODBOX_POLICY_AUTO && label_bytes > ((uint64_t)ODBOX_STREAM_MB << 20))) &&
+    const bool stream_out = (policy == ODBOX_POLICY_STREAM ||
+                             (policy == ODBOX_POLICY_AUTO && label_bytes > ((uint64_t)ODBOX_STREAM_MB << 20) && G <= STREAM_AUTO_MAX_G)) &&
                             d >= (uint32_t)STREAM_MIN_ROW;
     const bool sweep = sweep_applies(label_bytes, B, G, d, labels_aligned16 != 0, want_gt_best != 0);
     if (policy == ODBOX_POLICY_AUTO && !stream_out) return sweep ? ODBOX_PLAN_SWEEP : ODBOX_PLAN_TILES;      // a buffer not written a moment ago

@@ -213,6 +213,7 @@ def test_every_entry_rejects_bad_arguments_without_touching_the_gpu(lib):
     assert lib.odbox_match_encode_last_plan() == -1                                # no call yet on this thread
     assert lib.odbox_match_encode_plan(160, 10647, 20, 80, 1, 0) == 2              # 552 MB: streamed, wide rows, short GT list
     assert lib.odbox_match_encode_plan(32, 196416, 20, 80, 1, 0) == 1              # 2 GB: streamed tiles
+    assert lib.odbox_match_encode_plan(32, 196416, 81, 80, 1, 0) == 0              # ... but not with a long GT list
     assert lib.odbox_match_encode_plan(128, 49104, 500, 1, 1, 0) == 0
     assert lib.odbox_set_output_policy(2) == 0
     assert [lib.odbox_match_encode_plan(64, 10647, 20, 80, a, g) for a, g in ((1, 0), (0, 0), (1, 1))] == [2, 1, 1]

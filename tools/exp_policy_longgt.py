@@ -7,13 +7,14 @@ import bench
 from object_detection_amd import _lib, workloads
 lib = _lib.load(); dev = _lib.require_gpu(); st = _lib.stream_ptr()
 anchors = bench.yolo_grid_anchors(416)
-N, S, C, B = anchors.shape[0], 416, 80, 64
-for G in (65, 100, 200):
+N, S, C = anchors.shape[0], 416, 80
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+for G in [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (65, 100, 200):
     rng = np.random.default_rng(G)
     gts = [workloads.gt_boxes(rng, S, G, C) for _ in range(B)]
     gt = torch.as_tensor(np.stack([g[0] for g in gts])).to(dev)
     lab = torch.as_tensor(np.stack([g[1] for g in gts])).to(dev)
-    for sets in (1, 5):
+    for sets in ((1, 5) if B <= 64 else (1,)):
         regs = [torch.empty((B, N, 5), device=dev) for _ in range(sets)]
         labs = [torch.empty((B, N, C + 1), device=dev) for _ in range(sets)]
         def step(i):
@@ -23,8 +24,9 @@ for G in (65, 100, 200):
         out = []
         for pol in (1, 2, 0, 1, 2, 0):
             lib.odbox_set_output_policy(pol)
-            _, ev = bench.timed(step, 60, 10, 1)
-            out.append(ev / 60 * 1e6)
+            it = 60 if B <= 64 else 20
+            _, ev = bench.timed(step, it, 5, 1)
+            out.append(ev / it * 1e6)
         lib.odbox_set_output_policy(0)
         print('G %3d x %d set(s): cache %.1f / %.1f   stream %.1f / %.1f   auto %.1f / %.1f us (plan %d)'
               % (G, sets, out[0], out[3], out[1], out[4], out[2], out[5], lib.odbox_match_encode_last_plan()), flush=True)
