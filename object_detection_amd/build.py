@@ -17,7 +17,9 @@ COMMON = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-std=c+
           '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
 # translation unit -> extra flags (see the header comment of each file)
 UNITS = {
-    'odbox_train.hip': ['-fno-honor-nans'],
+    # the matcher's degenerate-box guards are NaN-aware comparisons (!(x >= 0)): NaNs are honoured in this unit
+    # (ODBOX_TRAIN_FLAGS: per-unit extra flags of a tuning build, e.g. the A/B that decided this)
+    'odbox_train.hip': os.environ.get('ODBOX_TRAIN_FLAGS', '').split(),
     'odbox_infer.hip': ['-fno-honor-nans'],
     'odbox_eval.hip': [],
 }
@@ -30,7 +32,8 @@ STAMP = os.path.join(OBJ, 'flags.txt')
 def tuning_flags():
     # ODBOX_TUNING_HOOKS=1: the library reads the ODBOX_SCAN_* / ODBOX_NMS_DBG experiment knobs (tools/exp_*.sh)
     hooks = ['-DODBOX_TUNING_HOOKS'] if os.environ.get('ODBOX_TUNING_HOOKS') == '1' else []
-    return hooks + os.environ.get('ODBOX_EXTRA_HIPCC_FLAGS', '').split()      # tuning builds only, e.g. -DODBOX_ME_TILE_ENC=512
+    return (hooks + os.environ.get('ODBOX_EXTRA_HIPCC_FLAGS', '').split()      # tuning builds only, e.g. -DODBOX_ME_TILE_ENC=512
+            + ['@train:' + f for f in os.environ.get('ODBOX_TRAIN_FLAGS', '').split()])
 
 
 def needs_build():
@@ -77,7 +80,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get('HIPCC', 'hipcc')
-    hooks = tuning_flags()
+    hooks = [f for f in tuning_flags() if not f.startswith('@train:')]
     os.makedirs(OBJ, exist_ok=True)
     objs = []
     for unit, extra in UNITS.items():
@@ -93,7 +96,7 @@ def build(force=False, verbose=False):
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)
     with open(STAMP, 'w') as f:
-        f.write(' '.join(hooks))
+        f.write(' '.join(tuning_flags()))
     return OUT
 
 

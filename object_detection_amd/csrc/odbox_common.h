@@ -49,6 +49,27 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblocks)
     return start + (bid >> 3);
 }
 
+// v_min_f32 / v_max_f32 as the hardware has them, for the matcher's hot loops.  fminf / fmaxf are llvm.minnum /
+// maxnum, which in IEEE mode put a canonicalising v_max_f32 x, x, x in front of every operand that comes out of a
+// load (a signalling NaN must be quieted first): +4 instructions per (anchor, GT) pair.  -fno-honor-nans removed them
+// (configs[3] 396 -> 343 us, the sweep's matcher waves 49.7 -> 39.1 us per launch, same-box A/B) but also told the
+// compiler that NO operation of the unit ever sees a NaN, while the matcher's degenerate-box guards and the 0/0
+// offsets of zero-size anchors rely on NaNs behaving as IEEE says.  So the unit is built WITHOUT that flag and only
+// these two instructions are taken as they are: a number beats a quiet NaN, two numbers compare as in fminf / fmaxf.
+// Plain asm (not volatile): the compiler may move, merge or drop them like any pure instruction.
+__device__ __forceinline__ float vmin(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // x / d and x % d for x*e < d*2^32 with m = floor(2^32 / d): one mulhi and one fix-up.
 __device__ __forceinline__ void divmod_u32(uint32_t x, uint32_t d, uint32_t m, uint32_t &q, uint32_t &r)
 {

@@ -58,11 +58,11 @@ __global__ __launch_bounds__(256) void anchor_tile_kernel(const float4 *__restri
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float pair_iou(const float4 a, float a_area, const float4 g, float g_area)
 {
-    float ix0 = fmaxf(a.x, g.x);
-    float ix1 = fminf(a.z, g.z);
-    float iy0 = fmaxf(a.y, g.y);
-    float iy1 = fminf(a.w, g.w);
-    float i_area = fmaxf(ix1 - ix0, 0.0f) * fmaxf(iy1 - iy0, 0.0f);
+    float ix0 = vmax(a.x, g.x);
+    float ix1 = vmin(a.z, g.z);
+    float iy0 = vmax(a.y, g.y);
+    float iy1 = vmin(a.w, g.w);
+    float i_area = vmax(ix1 - ix0, 0.0f) * vmax(iy1 - iy0, 0.0f);
     float u_area = ((a_area + g_area) - i_area) + 1e-8f;
     return i_area / u_area;
 }
@@ -189,15 +189,16 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
     // the same way.  Dead lanes (n >= N) do not widen the box.
     float wx0 = live ? a.x : INFINITY, wy0 = live ? a.y : INFINITY;
     float wx1 = live ? a.z : -INFINITY, wy1 = live ? a.w : -INFINITY;
-    float wmin_area = live ? a_area : INFINITY;
+    // every live anchor of the wave has a finite area >= 0 (false for a negative, infinite or NaN area: the
+    // comparisons are ordered ones and the unit is built with NaNs honoured)
+    const bool can_skip_zero = __ballot(live && !(a_area >= 0.0f && a_area < INFINITY)) == 0ull;
     auto reduce_box = [&] {
 #pragma unroll
         for (int off = 1; off < WAVE; off <<= 1) {
-            wx0 = fminf(wx0, __shfl_xor(wx0, off));
-            wy0 = fminf(wy0, __shfl_xor(wy0, off));
-            wx1 = fmaxf(wx1, __shfl_xor(wx1, off));
-            wy1 = fmaxf(wy1, __shfl_xor(wy1, off));
-            wmin_area = fminf(wmin_area, __shfl_xor(wmin_area, off));
+            wx0 = vmin(wx0, __shfl_xor(wx0, off));
+            wy0 = vmin(wy0, __shfl_xor(wy0, off));
+            wx1 = vmax(wx1, __shfl_xor(wx1, off));
+            wy1 = vmax(wy1, __shfl_xor(wy1, off));
         }
     };
     if (!REDUCE_LATE) reduce_box();
@@ -213,7 +214,7 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
         for (int g = tid; g < cnt; g += TILE) {
             float4 gb = gtb[g0 + g];
             float area = (gb.w - gb.y) * (gb.z - gb.x);                  // bndbox.py:286
-            float gmax = fmaxf(fmaxf(gb.x, gb.y), fmaxf(gb.z, gb.w));    // bndbox.py:295
+            float gmax = vmax(vmax(gb.x, gb.y), vmax(gb.z, gb.w));    // bndbox.py:295
             s_gt[g] = gb;
             s_ga[g] = make_float2(area, gmax < 0.0f ? 1.0f : 0.0f);
             if (GTBEST) {
@@ -230,10 +231,9 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
             if (REDUCE_LATE) reduce_box();
         }
         __syncthreads();
-        const bool can_skip_zero = wmin_area >= 0.0f;      // false also for NaN
         // this wave's work list: 64 GT rows per step, one per lane, order preserved
         uint32_t nlist = 0;
-        uint64_t odd_rows = 0ull;                          // listed rows whose area is negative (or NaN)
+        uint64_t odd_rows = 0ull;                          // listed rows whose area is negative, infinite or NaN
         for (int gs = 0; gs < cnt; gs += WAVE) {
             const int g = gs + (int)lane;
             bool is_pad = false, is_zero = false;
@@ -246,7 +246,10 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
             }
             const bool keep = g < cnt && !is_pad && !is_zero;
             const uint64_t mk = __ballot(keep), mz = __ballot(is_zero), mp = __ballot(is_pad);
-            odd_rows |= __ballot(keep && !(s_ga[min(g, cnt - 1)].x >= 0.0f));
+            {
+                const float ga_x = s_ga[min(g, cnt - 1)].x;
+                odd_rows |= __ballot(keep && !(ga_x >= 0.0f && ga_x < INFINITY));
+            }
             if (keep) s_list[wave][nlist + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)g;
             nlist += (uint32_t)__popcll(mk);
             if (first_zero < 0 && mz != 0ull) first_zero = g0 + gs + __ffsll((unsigned long long)mz) - 1;
@@ -255,7 +258,8 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        // ---- the usual case, division-free: every area in play is >= 0, so every IoU is >= +0 ----------
+        // ---- the usual case, division-free: every area in play is finite and >= 0, so every IoU is a number >= +0
+        // (an intersection is at most the smaller area, hence finite; a sum of areas that overflows gives 0) --------
         // The correctly rounded division is 13 of the ~29 issue cycles of a pair, and all the argmax needs
         // from it is "is this row's quotient greater than the best so far".  q = i * rcp(u) is within
         // 2^-22 of the true ratio (v_rcp_f32: 1 ulp), the rounded quotients within 2^-24: two rows whose q
@@ -297,9 +301,9 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
                 for (int r = 0; r < R; ++r) {
                     const float4 gb = s_gt[g[r]];
                     const float g_area = s_ga[g[r]].x;
-                    const float ix0 = fmaxf(a.x, gb.x), ix1 = fminf(a.z, gb.z);
-                    const float iy0 = fmaxf(a.y, gb.y), iy1 = fminf(a.w, gb.w);
-                    ia[r] = fmaxf(ix1 - ix0, 0.0f) * fmaxf(iy1 - iy0, 0.0f);
+                    const float ix0 = vmax(a.x, gb.x), ix1 = vmin(a.z, gb.z);
+                    const float iy0 = vmax(a.y, gb.y), iy1 = vmin(a.w, gb.w);
+                    ia[r] = vmax(ix1 - ix0, 0.0f) * vmax(iy1 - iy0, 0.0f);
                     ua[r] = ((a_area + g_area) - ia[r]) + 1e-8f;                         // bndbox.py:289, > 0 here
                     q[r] = ia[r] * __builtin_amdgcn_rcpf(ua[r]);
                 }
@@ -342,10 +346,10 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
                             if (__ballot(reach[r] && live) == 0ull) continue;
                             // the wave's largest quotient (all >= 0: their bits order like integers)
                             float m = reach[r] && live ? q[r] : 0.0f;
-                            m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0xB1, 0xf, 0xf, true)));    // quad_perm [1,0,3,2]
-                            m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x4E, 0xf, 0xf, true)));    // quad_perm [2,3,0,1]
-                            m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x141, 0xf, 0xf, true)));   // row_half_mirror
-                            m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x140, 0xf, 0xf, true)));   // row_mirror
+                            m = vmax(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0xB1, 0xf, 0xf, true)));    // quad_perm [1,0,3,2]
+                            m = vmax(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x4E, 0xf, 0xf, true)));    // quad_perm [2,3,0,1]
+                            m = vmax(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x141, 0xf, 0xf, true)));   // row_half_mirror
+                            m = vmax(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x140, 0xf, 0xf, true)));   // row_mirror
                             const uint32_t mb = max(max((uint32_t)__builtin_amdgcn_readlane(__float_as_int(m), 0),
                                                         (uint32_t)__builtin_amdgcn_readlane(__float_as_int(m), 16)),
                                                     max((uint32_t)__builtin_amdgcn_readlane(__float_as_int(m), 32),
@@ -670,7 +674,7 @@ __global__ __launch_bounds__(WAVE *(SWEEP_SW + SWEEP_MW)) void match_encode_swee
             for (uint32_t k = 0; k < K; ++k) {
                 const uint32_t bk = b0 + k * SWEEP_MW;
                 if (bk >= B) break;
-                const bool pad = fmaxf(fmaxf(row[k].x, row[k].y), fmaxf(row[k].z, row[k].w)) < 0.0f;      // bndbox.py:295
+                const bool pad = vmax(vmax(row[k].x, row[k].y), vmax(row[k].z, row[k].w)) < 0.0f;      // bndbox.py:295
                 const uint64_t valid = __ballot(!pad && lane < (uint32_t)G);
                 const uint32_t bound = valid ? 64u - (uint32_t)__clzll((long long)valid) : 0u;
                 if (lane < min(bound, gs)) {
@@ -718,7 +722,7 @@ __global__ __launch_bounds__(WAVE *(SWEEP_SW + SWEEP_MW)) void match_encode_swee
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float area = (gb[k].w - gb[k].y) * (gb[k].z - gb[k].x);                     // bndbox.py:286
-                const bool pad = fmaxf(fmaxf(gb[k].x, gb[k].y), fmaxf(gb[k].z, gb[k].w)) < 0.0f;  // bndbox.py:295
+                const bool pad = vmax(vmax(gb[k].x, gb[k].y), vmax(gb[k].z, gb[k].w)) < 0.0f;  // bndbox.py:295
                 const float v = pad ? -1.0f : pair_iou(a, a_area, gb[k], area);
                 if (g0 + k < lim && v > best_iou) { best_iou = v; best = g0 + k; }
             }
@@ -826,7 +830,7 @@ template <bool G15, bool GRAD>
 __device__ __forceinline__ float focal_term(float pred, bool y, const LossParams lp, float &grad)
 {
     const float eps = 1e-6f, ln2 = 0.69314718f;
-    const float p = fminf(fmaxf(pred, eps), 1.0f - eps);                 // metric.py:22-23
+    const float p = vmin(vmax(pred, eps), 1.0f - eps);                 // metric.py:22-23
     const float q = 1.0f - p;
     const float pt = y ? p : q;                                          // :28
     const float om = 1.0f - pt;
@@ -1313,7 +1317,7 @@ __global__ __launch_bounds__(256) void gt_best_finalize_kernel(const float4 *__r
     const float4 gb = gt[i];                                         // i = b * G + g
     const float a_area = (a.w - a.y) * (a.z - a.x);
     const float g_area = (gb.w - gb.y) * (gb.z - gb.x);
-    const float gmax = fmaxf(fmaxf(gb.x, gb.y), fmaxf(gb.z, gb.w));
+    const float gmax = vmax(vmax(gb.x, gb.y), vmax(gb.z, gb.w));
     const float v = gmax < 0.0f ? -1.0f : pair_iou(a, a_area, gb, g_area);       // bndbox.py:289-297
     int2 rec;
     rec.x = (int)n;
@@ -1340,7 +1344,7 @@ __global__ __launch_bounds__(256) void bbox_overlap_kernel(const float4 *__restr
     float a_area = (a.w - a.y) * (a.z - a.x);
     float g_area = (gb.w - gb.y) * (gb.z - gb.x);
     float v = pair_iou(a, a_area, gb, g_area);
-    float gmax = fmaxf(fmaxf(gb.x, gb.y), fmaxf(gb.z, gb.w));
+    float gmax = vmax(vmax(gb.x, gb.y), vmax(gb.z, gb.w));
     out[t] = gmax < 0.0f ? -1.0f : v;
 }
 

@@ -92,12 +92,15 @@ void odbox_oracle_match_encode(const float *anchors, const float *gt_boxes, cons
         const int32_t *glb = gt_labels ? gt_labels + (size_t)b * G : NULL;
         for (int n = 0; n < N; ++n) {
             const float *a = anchors + (size_t)n * 4;
-            /* tf.argmax / tf.reduce_max (anchors.py:255-256): first maximal index */
+            /* tf.argmax / tf.reduce_max (anchors.py:255-256): first maximal index.  Eigen's reducers start from
+             * (index 0, lowest) and replace on a strict >, so a NaN overlap (inf - inf: boxes whose areas overflow
+             * binary32) never wins and never blocks a later row; a row of NaNs only gives (0, -inf) here -- Eigen's
+             * own value there depends on its packet path and is outside any contract (finite inputs). */
             int best = 0;
-            float best_iou = 0.0f;
+            float best_iou = -INFINITY;
             for (int g = 0; g < G; ++g) {
                 float v = overlap_pair(a, gtb + (size_t)g * 4);
-                if (g == 0 || v > best_iou) { best = g; best_iou = v; }
+                if (v > best_iou) { best = g; best_iou = v; }
             }
             int positive = best_iou >= pos_thr;                                  /* :267 */
             int ignore = ((best_iou > neg_thr) && !positive) || (best_iou < 0.0f); /* :270-272 */

@@ -121,6 +121,9 @@ def compute_gt_annotations(anchors, annotations, negative_overlap=0.4, positive_
     maxv = np.empty((B, N), dtype=F32)
     for b in range(B):  # image by image so the [N,G] matrix stays small
         ov = bbox_overlap(anchors[None], annotations[b:b + 1])[0]
+        # Eigen's argmax / max reducers start from (0, lowest) and replace on a strict >: a NaN overlap (inf - inf,
+        # only possible when a box area overflows binary32) never wins; numpy's would.  Same rule as odbox_oracle.c.
+        ov = np.where(np.isnan(ov), F32(-np.inf), ov)
         argmax[b] = ov.argmax(axis=-1).astype(I32)
         maxv[b] = ov.max(axis=-1)
     positive = maxv >= F32(positive_overlap)

@@ -151,6 +151,48 @@ def test_degenerate_boxes(stream_policy):
         check(a, (256, 256), gt, lab, 80)
 
 
+def test_boxes_whose_areas_overflow(stream_policy):
+    """Finite coordinates of 1e19 .. 3e38: areas overflow to +inf, unions to inf - inf = NaN, a zero-width anchor of
+    infinite height has area inf * 0 = NaN, offsets divide by inf.  The unit is built with NaNs honoured and the matcher
+    sends every wave or row with a non-finite area through its exact loop, where a NaN overlap never wins (the rule of
+    Eigen's reducers, oracle/odbox_oracle.c): the sweep, the 256-anchor tiles, the streaming tiles and the oracle must
+    agree on every output."""
+    rng = np.random.default_rng(1020)
+    anchors = O.generate_anchors(256)
+    N = anchors.shape[0]
+    huge = anchors.copy()
+    huge[3::97] = [-1e20, -1e20, 1e20, 1e20]                 # area inf
+    huge[5::101] = [0, 0, 3e38, 3e38]                        # sides finite, area inf
+    huge[7::103] = [5, -3e38, 5, 3e38]                       # width 0, height inf: area NaN
+    huge[11::107] = [-3e38, 10, 3e38, 20]                    # width inf
+    huge[13::109] = [1e19, 1e19, 3e19, 3e19]                 # far away and huge
+    G = 24
+    gts = [workloads.gt_boxes(rng, 256, G - 4, 80, pad_to=G) for _ in range(5)]
+    gt = np.stack([g[0] for g in gts])
+    lab = np.stack([g[1] for g in gts])
+    gt[0, 0] = [-1e20, -1e20, 1e20, 1e20]                    # NaN overlap with the huge anchors in the FIRST row
+    gt[1, 5] = [0, 0, 3e38, 3e38]
+    gt[1, 6] = [-1e20, -1e20, 1e20, 1e20]
+    gt[2, :G - 4] = [-1e20, -1e20, 1e20, 1e20]               # every valid row: NaN or 0 for everybody
+    gt[3, 2] = [5, -3e38, 5, 3e38]                           # a NaN-area row
+    gt[3, 3] = [100, 100, 3e38, 120]
+    gt[4, 1] = [1e19, 1e19, 3e19, 3e19]
+    with np.errstate(over='ignore', invalid='ignore'):
+        for a in (huge, anchors):
+            check(a, (256, 256), gt, lab, 80)
+        # the streaming tiles (a GT list too long for the sweep) and, under 'cache', the 256-anchor tiles again
+        gt65 = np.concatenate([gt, np.full((5, 65 - G, 4), -1, F)], 1)
+        lab65 = np.concatenate([lab, np.full((5, 65 - G), -1, np.int32)], 1)
+        gt65[:, 64] = [-1e20, 0, 1e20, 3e38]
+        lab65[:, 64] = 7
+        assert A.match_encode_plan(5, N, 65, 80) == 'tiles_stream'
+        got = A.match_encode(huge, (256, 256), gt65, lab65, 80, dense=True, compact=True)
+        ref = c_oracle.match_encode(huge, (256, 256), gt65, lab65, 80, 0.4, 0.5, threads=8)
+        for k in ('match_idx', 'state', 'max_iou', 'labels'):
+            np.testing.assert_array_equal(cpu(got[k]), ref[k])
+        np.testing.assert_allclose(cpu(got['regression']), ref['regression'], rtol=1e-5, atol=0, equal_nan=True)
+
+
 def test_ties_and_near_ties(stream_policy):
     """Rows that tie exactly and rows a few ulps apart: the sweep's exact divisions against the tile kernel's
     division-free loop with its exact fallback, and the oracle."""
