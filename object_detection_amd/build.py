@@ -60,8 +60,17 @@ def check_m0(hipcc, hooks, verbose=False):
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)
-    lines = [l.split(';')[0].strip() for l in open(asm)]
-    lines = [l for l in lines if l and not l.startswith(('.', '//'))]
+    # only the kernels that issue the LDS-DMA (score_scan_kernel<...>) matter: elsewhere the compiler is free to
+    # use M0 (e.g. as the lane select of a v_readlane in the NMS kernel)
+    lines, inside = [], False
+    for raw in open(asm):
+        l = raw.split(';')[0].strip()
+        if l.endswith(':') and not l.startswith('.'):
+            inside = 'score_scan_kernel' in l
+        elif l.startswith('.Lfunc_end'):
+            inside = False
+        elif inside and l and not l.startswith(('.', '//')):
+            lines.append(l)
     sets = 0
     for i, l in enumerate(lines):
         if 'm0' not in l.replace(',', ' ').split():

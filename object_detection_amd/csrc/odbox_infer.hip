@@ -153,6 +153,36 @@ struct VecLoad<4> {
 #define ODBOX_NO_EXPERIMENTS(word) ((word) = 0u)
 #endif
 
+// Phase stamps of the tail kernels, diagnostic builds only (-DODBOX_STAMPS, tools/exp_nms_stamps.py): every wave (or
+// block) adds the length of each of its phases, in 10 ns ticks of the constant-rate clock, to a sum and a maximum.
+// Each stamp drains the wave's memory operations first, so such a build is slower and only the SHARES mean anything.
+#ifdef ODBOX_STAMPS
+__device__ unsigned long long g_stamp_sum[64], g_stamp_max[64], g_stamp_cnt[64];
+struct Stamps {
+    unsigned long long t;
+    __device__ __forceinline__ Stamps() : t(now()) {}
+    static __device__ __forceinline__ unsigned long long now()
+    {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        return wall_clock64();
+    }
+    __device__ __forceinline__ void lap(int slot, bool leader)
+    {
+        const unsigned long long n = now();
+        if (leader) {
+            atomicAdd(&g_stamp_sum[slot], n - t);
+            atomicMax(&g_stamp_max[slot], n - t);
+            atomicAdd(&g_stamp_cnt[slot], 1ull);
+        }
+        t = now();
+    }
+};
+#define ODBOX_LAP(st, slot, leader) (st).lap((slot), (leader))
+#else
+struct Stamps {};
+#define ODBOX_LAP(st, slot, leader) ((void)0)
+#endif
+
 constexpr uint32_t SCAN_QUEUES = 64;       // ticket counters (tile queues)
 constexpr uint32_t SCAN_TICKET_STRIDE = 64;   // ints between counters: atomics on one cache line serialise
 constexpr uint32_t SCAN_MAX_ROWS = 512;    // rows per tile; also the size of the pending-key list
@@ -183,8 +213,29 @@ __device__ __forceinline__ float h16_widen(uint32_t bits16, bool bf16)
     return bf16 ? __uint_as_float(bits16 << 16) : (float)__builtin_bit_cast(_Float16, (uint16_t)bits16);
 }
 
+// The call's counters are zeroed INSIDE its first kernel (round 3; a zero_header_kernel in front of the scan cost
+// 4.6 us plus a kernel boundary on every call).  The workspace starts with two 64-bit words on a 256-byte line of
+// their own: `epoch`, which the last kernel of every call raises by one, and `ready`.  Block 0 of the scan zeroes
+// every counter of the call (write-through stores, drained) and then stores ready = epoch + 1; every other wave
+// polls `ready` for that value before its first atomic on a counter -- its first tile is assigned statically and
+// its DMA is already in flight by then.  Both words live in device memory, so a replayed HIP graph works like an
+// eager call (a per-call host value would be frozen at capture).  A workspace with arbitrary contents is fine:
+// the stale `ready` of an earlier call is epoch, not epoch + 1, and garbage equals epoch + 1 with probability
+// 2^-64.  Only a call whose launches fail half-way (ODBOX_EHIP) leaves the two words in an undefined relation:
+// zero the first 16 bytes of the workspace, or take a fresh one, before using it again (include/odbox.h).
+constexpr size_t HDR_BYTES = 256;
+typedef unsigned long long hdr_word;
+__device__ __forceinline__ void wait_ready(hdr_word *hdr, hdr_word want)
+{
+    // bounded: ~0.2 s of polling, then go on (wrong detections, never a hang)
+    for (uint32_t spins = 0; spins < (1u << 17); ++spins) {
+        if (__hip_atomic_load(hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 template <int V, int LL, bool HALF>
-__global__ __launch_bounds__(WAVE) void score_scan_kernel(
+__global__ __launch_bounds__(WAVE) void score_scan_kernel(hdr_word *hdr, uint32_t B, int *coop_count,
     const float *__restrict__ scores, int N, int C, ScanGeom g, float score_thr, uint32_t tiles_per_image,
     uint32_t total_tiles, int *__restrict__ tile_ticket, int *__restrict__ cand_count,
     uint64_t *__restrict__ cand_keys, uint32_t cand_stride, uint32_t nq_arg, uint32_t half_mode, uint32_t dbg)
@@ -229,6 +280,17 @@ __global__ __launch_bounds__(WAVE) void score_scan_kernel(
     // of the previous tile) are issued at the top, BEFORE the iteration's one s_waitcnt
     // vmcnt(0), where only the current tile is outstanding; the DMAs of the next tile go out
     // after it; and the reduce phase issues no vector-memory instruction at all.
+    const hdr_word want = hdr[0] + 1ull;                              // written by the last kernel of the previous call
+    if (blockIdx.x == 0) {
+        // cand_count[B] and fin_count[B] (one 256-byte line each, adjacent arrays), the tile tickets, coop_count
+        for (uint32_t i = lane; i < 2u * B; i += WAVE)
+            __hip_atomic_store(cand_count + (size_t)i * CNT_STRIDE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < SCAN_QUEUES)
+            __hip_atomic_store(tile_ticket + lane * SCAN_TICKET_STRIDE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(coop_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every zero has left this wave
+        if (lane == 0) __hip_atomic_store(hdr + 1, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const uint32_t nq = min(nq_arg, gridDim.x);                       // every queue has a block
     const uint32_t q = blockIdx.x % nq;
     const uint32_t q_lo = (uint32_t)(((uint64_t)total_tiles * q) / nq);
@@ -243,6 +305,7 @@ __global__ __launch_bounds__(WAVE) void score_scan_kernel(
     uint32_t t = q_lo + blockIdx.x / nq;
     if (t >= q_hi) return;
     issue(t, 0);
+    if (blockIdx.x != 0) wait_ready(hdr, want);                       // the counters are zero from here on
     uint32_t nt = draw();
     uint32_t pend_n = 0, pend_b = 0;
 
@@ -568,9 +631,15 @@ constexpr int NMS_COOP_MIN = ODBOX_NMS_COOP_MIN;          // segments above this
 #endif
 constexpr int PART_THREADS = ODBOX_PART_THREADS;
 
+// The class histogram is kept in PART_COPIES copies, one per lane & (PART_COPIES - 1): candidates arrive in runs of one
+// class (neighbouring anchors of one object), and lanes that add to one LDS word are served one after the other --
+// 64 per instruction with a single copy, 8 with eight (stamps, one image: histogram 3.0 -> 1.6 us, scatter 2.3 ->
+// 1.3 us).  Many classes: one copy (the copies must fit beside the sort buffer).
+constexpr int PART_COPIES = 8;
+__host__ __device__ constexpr int part_copies(int C) { return C <= 128 ? PART_COPIES : 1; }
 __host__ __device__ constexpr size_t part_sort_offset(int C)      // byte offset of the sort buffer behind hist + scan scratch
 {
-    return ((size_t)(C + PART_THREADS + 1) * sizeof(int) + 15) & ~(size_t)15;
+    return ((size_t)(C * part_copies(C) + PART_THREADS + 1) * sizeof(int) + 15) & ~(size_t)15;
 }
 // what six resident scan waves really leave of a CU's LDS (see TAIL_LDS_RESERVE): the tail kernels must fit into it at
 // the configuration the pipeline is measured on, or two batches in flight silently stop overlapping
@@ -591,10 +660,14 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
     int *__restrict__ coop_list)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_part[];
-    int *s_hist = reinterpret_cast<int *>(s_part);       // [C] counts -> cursors
-    int *s_scan = s_hist + C;                            // [PART_THREADS] scan scratch, [PART_THREADS] = flag
+    const int copies = part_copies(C);
+    int *s_hist = reinterpret_cast<int *>(s_part);       // [copies][C] counts -> cursors
+    int *s_scan = s_hist + copies * C;                   // [PART_THREADS] scan scratch, [PART_THREADS] = flag
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    int *my_hist = s_hist + (int)(tid & (uint32_t)(copies - 1)) * C;      // this lane's copy
+    Stamps stp;
     uint32_t M = min((uint32_t)cand_count[b * CNT_STRIDE], cand_stride);
+    ODBOX_LAP(stp, 0, tid == 0);                          // count loaded
     uint64_t *in = keys_in + (size_t)b * cand_stride;
     uint64_t *out = keys_out + (size_t)b * cand_stride;
     if (pre_nms_topk != 0u && M > pre_nms_topk) {        // block-uniform
@@ -614,7 +687,7 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
         M = pre_nms_topk;
         __syncthreads();                                 // the cut list is what every thread reads below
     }
-    for (int c = tid; c < C; c += PART_THREADS) s_hist[c] = 0;
+    for (int c = tid; c < copies * C; c += PART_THREADS) s_hist[c] = 0;
     if (tid == 0) s_scan[PART_THREADS] = 0;
     __syncthreads();
     // (class / anchor ids are clamped wherever they index memory: a corrupted workspace must give
@@ -633,16 +706,26 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
         }
 #pragma unroll
         for (int r = 0; r < PART_REG; ++r)
-            if (tid + (uint32_t)r * PART_THREADS < M) atomicAdd(&s_hist[min(key_class(kreg[r]), cmax)], 1);
+            if (tid + (uint32_t)r * PART_THREADS < M) atomicAdd(&my_hist[min(key_class(kreg[r]), cmax)], 1);
     } else {
-        for (uint32_t i = tid; i < M; i += PART_THREADS) atomicAdd(&s_hist[min(key_class(in[i]), cmax)], 1);
+        for (uint32_t i = tid; i < M; i += PART_THREADS) atomicAdd(&my_hist[min(key_class(in[i]), cmax)], 1);
     }
     __syncthreads();
+    ODBOX_LAP(stp, 1, tid == 0);                          // keys loaded, histogram built
     // exclusive scan over classes: each thread owns a contiguous chunk; wave scans + 8 wave totals
     const int chunk = (C + PART_THREADS - 1) / PART_THREADS;
     const int c0 = min((int)tid * chunk, C), c1 = min(c0 + chunk, C);
+    auto class_count = [&](int c) {
+        int n = 0;
+        for (int k = 0; k < copies; ++k) n += s_hist[k * C + c];
+        return n;
+    };
     int local = 0, biggest = 0;
-    for (int c = c0; c < c1; ++c) { local += s_hist[c]; biggest = max(biggest, s_hist[c]); }
+    for (int c = c0; c < c1; ++c) {
+        const int n = class_count(c);
+        local += n;
+        biggest = max(biggest, n);
+    }
     if (biggest > (int)NMS_SEG_LDS) s_scan[PART_THREADS] = 1;
     int incl = local;
 #pragma unroll
@@ -656,9 +739,13 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
     for (uint32_t w = 0; w < (tid >> 6); ++w) run += s_scan[w];
     int *seg = seg_start + (size_t)b * (C + 1);
     for (int c = c0; c < c1; ++c) {
-        const int cnt = s_hist[c];
         seg[c] = run;
-        s_hist[c] = run;                 // becomes the scatter cursor
+        int cnt = 0;
+        for (int k = 0; k < copies; ++k) {   // each copy becomes the scatter cursor of its lanes
+            const int n = s_hist[k * C + c];
+            s_hist[k * C + c] = run + cnt;
+            cnt += n;
+        }
         // segments of NMS_COOP_MIN < m <= NMS_SEG_LDS candidates go to the cooperative blocks of the NMS kernel
         if (cnt > NMS_COOP_MIN && cnt <= (int)NMS_SEG_LDS) {
             const uint32_t at = (uint32_t)atomicAdd(coop_count, 1);
@@ -669,26 +756,29 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
     if (tid == 0) seg[C] = (int)M;
     const bool big = s_scan[PART_THREADS] != 0;
     __syncthreads();
+    ODBOX_LAP(stp, 2, tid == 0);                          // class scan, segment starts, cooperative list
     if (in_regs) {
 #pragma unroll
         for (int r = 0; r < PART_REG; ++r)
             if (tid + (uint32_t)r * PART_THREADS < M) {
-                const uint32_t at = (uint32_t)atomicAdd(&s_hist[min(key_class(kreg[r]), cmax)], 1);
+                const uint32_t at = (uint32_t)atomicAdd(&my_hist[min(key_class(kreg[r]), cmax)], 1);
                 if (at < M) out[at] = kreg[r];
             }
     } else {
         for (uint32_t i = tid; i < M; i += PART_THREADS) {
             const uint64_t k = in[i];
-            const uint32_t at = (uint32_t)atomicAdd(&s_hist[min(key_class(k), cmax)], 1);
+            const uint32_t at = (uint32_t)atomicAdd(&my_hist[min(key_class(k), cmax)], 1);
             if (at < M) out[at] = k;
         }
     }
+    ODBOX_LAP(stp, 3, tid == 0);                          // scatter
     if (!big) return;                                    // block-uniform
-    __syncthreads();                                     // scatter visible to the whole block; s_hist[c] = end of segment c
+    __syncthreads();                                     // scatter visible to the whole block; the last copy's cursor = end of segment c
     uint64_t *s_keys = reinterpret_cast<uint64_t *>(s_part + part_sort_offset(C));
+    const int *s_end = s_hist + (copies - 1) * C;
     for (int c = 0; c < C; ++c) {                        // every test below is block-uniform
-        const uint32_t st = c > 0 ? min((uint32_t)s_hist[c - 1], M) : 0u;
-        const uint32_t en = min((uint32_t)s_hist[c], M);
+        const uint32_t st = c > 0 ? min((uint32_t)s_end[c - 1], M) : 0u;
+        const uint32_t en = min((uint32_t)s_end[c], M);
         if (en <= st || en - st <= NMS_SEG_LDS) continue;
         const uint32_t m = en - st;
         if (m <= PART_SORT_CAP) {
@@ -814,12 +904,15 @@ __device__ __forceinline__ void nms_wave_segment(
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t seg_id = block * (uint32_t)waves_per_block + wave;
     if (seg_id >= total_segments) return;
+    Stamps stp;
     const uint32_t b = seg_id / (uint32_t)C;
     const uint32_t c = seg_id - b * (uint32_t)C;
     const int start = seg_start[(size_t)b * (C + 1) + c];
     const int end = seg_start[(size_t)b * (C + 1) + c + 1];
     if (end <= start) return;
     const uint32_t m = (uint32_t)(end - start);
+    const int sl = m <= 16 ? 8 : m <= WAVE ? 16 : 24;     // stamp slots by segment size: tiny / one chunk / two chunks
+    ODBOX_LAP(stp, sl + 0, lane == 0);                    // segment bounds loaded
 
     // per-wave LDS: [sorted segment keys: sort_cap][kept keys: max_ret][kept boxes and areas
     // beyond the register-resident NMS_REG_KEPT: extra * 20 bytes]
@@ -872,8 +965,10 @@ __device__ __forceinline__ void nms_wave_segment(
         uint64_t key0, key1 = 0ull;
         float4 nb0, nb1 = make_float4(0.f, 0.f, 0.f, 0.f);
         float ar0, ar1 = 0.0f;
+        ODBOX_LAP(stp, sl + 1, lane == 0);                                // keys loaded and sorted
         fetch(lane, key0, nb0, ar0);
         if (m > WAVE) fetch(WAVE + lane, key1, nb1, ar1);                 // both gathers in flight together
+        ODBOX_LAP(stp, sl + 2, lane == 0);                                // boxes gathered
         unsigned long long kmask0 = 0ull, kmask1 = 0ull;
         int kept = 0;
         unsigned long long mask = __ballot(lane < m);
@@ -909,9 +1004,11 @@ __device__ __forceinline__ void nms_wave_segment(
                 mask &= ~(__ballot(h1) | ((2ull << j) - 1ull));
             }
         }
+        ODBOX_LAP(stp, sl + 3, lane == 0);                                // greedy walk
         int base = 0;
         if (lane == 0) base = atomicAdd(fin_count + b * CNT_STRIDE, kept);
         base = __shfl(base, 0);
+        ODBOX_LAP(stp, sl + 4, lane == 0);                                // slot reservation
         const unsigned long long below = (1ull << lane) - 1ull;
         if ((kmask0 >> lane) & 1ull) {
             const uint32_t pos = (uint32_t)(base + __popcll(kmask0 & below));
@@ -1153,15 +1250,6 @@ __device__ __forceinline__ void nms_coop_block(
     }
 }
 
-// kernel 0: zero the header of the workspace (counters, flags, tile tickets).  A kernel of our own
-// rather than hipMemsetAsync: under HIP graph capture the memset node was observed to race with
-// the scan that follows it (wrong counters on replay); a kernel node keeps stream order.
-__global__ __launch_bounds__(256) void zero_header_kernel(uint4 *__restrict__ p, uint32_t n16)
-{
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
-}
-
 // kernel 3: the first coop_blocks blocks take the big segments cooperatively (they start first, so
 // the longest chains overlap everything else), the others run one wave per (image, class) segment.
 __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
@@ -1202,13 +1290,16 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
     const float4 *__restrict__ anchors, const BoxSrc rb, int N, int do_clip, float hi_x,
     float hi_y, int max_ret, const int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys,
     uint32_t fin_stride, uint32_t lds_keys, float4 *__restrict__ out_boxes, float *__restrict__ out_scores,
-    int32_t *__restrict__ out_labels, int32_t *__restrict__ out_keep, int32_t *__restrict__ out_count)
+    int32_t *__restrict__ out_labels, int32_t *__restrict__ out_keep, int32_t *__restrict__ out_count, hdr_word *hdr)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    if (b == 0 && tid == 0) hdr[0] = hdr[0] + 1ull;           // the call's last kernel: next epoch (see wait_ready)
+    Stamps stp;
     uint64_t *gk = fin_keys + (size_t)b * fin_stride;
     const uint32_t n = min((uint32_t)fin_count[b * CNT_STRIDE], fin_stride);
     const uint32_t keep = min(n, (uint32_t)max_ret);
+    ODBOX_LAP(stp, 56, tid == 0);                             // count loaded
     auto emit = [&](auto k) {
         for (uint32_t r = tid; r < (uint32_t)max_ret; r += FIN_THREADS) {
             const size_t o = (size_t)b * max_ret + r;
@@ -1239,6 +1330,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
             const uint32_t nchunks = (cnt + FIN_CHUNK - 1) / FIN_CHUNK;
             for (uint32_t i = carry + tid; i < nchunks * FIN_CHUNK; i += FIN_THREADS) s_keys[i] = i < cnt ? gk[base + i - carry] : ~0ull;
             __syncthreads();
+            ODBOX_LAP(stp, 57, tid == 0);                     // keys in LDS
             for (uint32_t c = wave; c < nchunks; c += nwaves) {
                 uint64_t k[2];
                 uint64_t *ch = s_keys + c * FIN_CHUNK;
@@ -1268,9 +1360,11 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
             }
             base += take;
             carry = FIN_CHUNK;
+            ODBOX_LAP(stp, 58, tid == 0);                     // chunk sorts and merges
             if (base >= n) break;
         }
         emit(s_keys);
+        ODBOX_LAP(stp, 59, tid == 0);                         // winners decoded and stored
     } else if (n <= TAIL_SORT_CAP) {
         for (uint32_t i = tid; i < n; i += FIN_THREADS) s_keys[i] = gk[i];
         __syncthreads();
@@ -1313,8 +1407,8 @@ bool nms_layout(int B, int N, int C, int max_ret, NmsLayout &L)
     uint64_t fin = (uint64_t)C * (uint64_t)max_ret;
     if (fin > (uint64_t)N) fin = (uint64_t)N;
     L.fin_stride = (uint32_t)fin;
-    L.off_counts = 0;                                              // cand_count, fin_count (one 256-byte line per image), B spare ints; then the tile tickets
-    L.off_tickets = ((size_t)2 * B * CNT_STRIDE + align_up((size_t)B, 64) + CNT_STRIDE) * sizeof(int);   // ... spare[B], coop_count
+    L.off_counts = HDR_BYTES;                                      // epoch / ready line; then cand_count, fin_count (one 256-byte line per image), B spare ints; then the tile tickets
+    L.off_tickets = L.off_counts + ((size_t)2 * B * CNT_STRIDE + align_up((size_t)B, 64) + CNT_STRIDE) * sizeof(int);   // ... spare[B], coop_count
     L.off_seg = L.off_tickets + (size_t)SCAN_QUEUES * SCAN_TICKET_STRIDE * sizeof(int);
     L.off_coop = L.off_seg + align_up((size_t)B * (C + 1) * sizeof(int), 256);                      // coop_list[B*C]
     L.off_keys_a = L.off_coop + align_up((size_t)B * C * sizeof(int), 256);
@@ -1434,7 +1528,7 @@ int allow_lds(K kernel, size_t bytes)
 }
 
 template <int V, int LL, bool HALF>
-int launch_scan_inst(const float *scores, int B, int N, int C, const ScanGeom &g, float score_thr, int *tile_ticket,
+int launch_scan_inst(hdr_word *hdr, int *coop_count, const float *scores, int B, int N, int C, const ScanGeom &g, float score_thr, int *tile_ticket,
                      int *cand_count, uint64_t *cand_keys, uint32_t cand_stride, uint32_t half_mode, hipStream_t st)
 {
     const uint32_t R = (uint32_t)g.steps * (WAVE >> LL);
@@ -1466,19 +1560,19 @@ int launch_scan_inst(const float *scores, int B, int N, int C, const ScanGeom &g
     const uint64_t resident = (uint64_t)device_cu_count() * per_cu;
     const uint32_t grid = (uint32_t)(total < resident ? total : resident);
     if (int rc = allow_lds(score_scan_kernel<V, LL, HALF>, lds_alloc)) return rc;
-    hipLaunchKernelGGL((score_scan_kernel<V, LL, HALF>), dim3(grid), dim3(WAVE), lds_alloc, st, scores, N, C, g, score_thr,
+    hipLaunchKernelGGL((score_scan_kernel<V, LL, HALF>), dim3(grid), dim3(WAVE), lds_alloc, st, hdr, (uint32_t)B, coop_count, scores, N, C, g, score_thr,
                        (uint32_t)tiles, (uint32_t)total, tile_ticket, cand_count, cand_keys, cand_stride, nq, half_mode, dbg);
     return launch_status("score_scan");
 }
 
 // (C = dwords per row: classes for fp32 scores, classes / 2 for 16-bit ones)
 template <int V, bool HALF>
-int launch_scan(const float *scores, int B, int N, int C, const ScanGeom &g, float score_thr, int *tile_ticket,
+int launch_scan(hdr_word *hdr, int *coop_count, const float *scores, int B, int N, int C, const ScanGeom &g, float score_thr, int *tile_ticket,
                 int *cand_count, uint64_t *cand_keys, uint32_t cand_stride, uint32_t half_mode, hipStream_t st)
 {
 #define ODBOX_SCAN_CASE(LL)                                                                                  \
     case LL:                                                                                                 \
-        return launch_scan_inst<V, LL, HALF>(scores, B, N, C, g, score_thr, tile_ticket, cand_count, cand_keys,    \
+        return launch_scan_inst<V, LL, HALF>(hdr, coop_count, scores, B, N, C, g, score_thr, tile_ticket, cand_count, cand_keys,    \
                                              cand_stride, half_mode, st)
     switch (g.lpr_log2) {
         ODBOX_SCAN_CASE(0);
@@ -1494,6 +1588,23 @@ int launch_scan(const float *scores, int B, int N, int C, const ScanGeom &g, flo
 }
 
 }  // namespace
+
+#ifdef ODBOX_STAMPS
+extern "C" int odbox_debug_stamps(unsigned long long *sum, unsigned long long *mx, unsigned long long *cnt, int reset)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(sum, HIP_SYMBOL(g_stamp_sum), sizeof(g_stamp_sum)));
+    HIP_TRY(hipMemcpyFromSymbol(mx, HIP_SYMBOL(g_stamp_max), sizeof(g_stamp_max)));
+    HIP_TRY(hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_stamp_cnt), sizeof(g_stamp_cnt)));
+    if (reset) {
+        static const unsigned long long zero[64] = {0};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sum), zero, sizeof(zero)));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_max), zero, sizeof(zero)));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_cnt), zero, sizeof(zero)));
+    }
+    return 0;
+}
+#endif
 
 extern "C" {
 
@@ -1555,11 +1666,7 @@ int decode_nms_impl(const char *who, const float *anchors, const void *regress_o
     const float hi_x = img_w - 1.0f, hi_y = img_h - 1.0f;
     const BoxSrc rb = {regress_or_boxes, box_dtype};
 
-    {   // counters, flags, tile tickets (L.off_seg is a multiple of 256 bytes)
-        const uint32_t n16 = (uint32_t)(L.off_seg / 16);
-        hipLaunchKernelGGL(zero_header_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, (uint4 *)ws, n16);
-        if (int r0 = launch_status("zero_header")) return r0;
-    }
+    hdr_word *hdr = (hdr_word *)ws;                                // epoch, ready: the scan zeroes the counters itself
 
     // kernel 1: score scan -> unordered candidate keys per image
     // (16-bit scores: two classes per dword, so the scan sees a [B*N, C/2] matrix of dwords)
@@ -1573,13 +1680,13 @@ int decode_nms_impl(const char *who, const float *anchors, const void *regress_o
         // the packed integer maximum of the raw bits is the row maximum whenever that maximum is positive, which is
         // all a threshold >= 0 asks about; a negative threshold takes the order-mapped form (see the kernel)
         const uint32_t hm = (score_dtype == ODBOX_DTYPE_BF16 ? HALF_BF16 : 0u) | (score_thr >= 0.0f ? 0u : HALF_GENERAL);
-        rc = g.V == 4 ? launch_scan<4, true>(sp, B, N, Cd, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, hm, st)
-           : g.V == 2 ? launch_scan<2, true>(sp, B, N, Cd, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, hm, st)
-                      : launch_scan<1, true>(sp, B, N, Cd, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, hm, st);
+        rc = g.V == 4 ? launch_scan<4, true>(hdr, coop_count, sp, B, N, Cd, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, hm, st)
+           : g.V == 2 ? launch_scan<2, true>(hdr, coop_count, sp, B, N, Cd, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, hm, st)
+                      : launch_scan<1, true>(hdr, coop_count, sp, B, N, Cd, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, hm, st);
     } else {
-        rc = g.V == 4 ? launch_scan<4, false>(sp, B, N, Cd, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, 0u, st)
-           : g.V == 2 ? launch_scan<2, false>(sp, B, N, Cd, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, 0u, st)
-                      : launch_scan<1, false>(sp, B, N, Cd, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, 0u, st);
+        rc = g.V == 4 ? launch_scan<4, false>(hdr, coop_count, sp, B, N, Cd, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, 0u, st)
+           : g.V == 2 ? launch_scan<2, false>(hdr, coop_count, sp, B, N, Cd, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, 0u, st)
+                      : launch_scan<1, false>(hdr, coop_count, sp, B, N, Cd, g, score_thr, tile_ticket, cand_count, keys_a, L.cand_stride, 0u, st);
     }
     if (rc) return rc;
 
@@ -1635,7 +1742,7 @@ int decode_nms_impl(const char *who, const float *anchors, const void *regress_o
     hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(FIN_THREADS), fin_lds, st, (const float4 *)anchors,
                        rb, N, do_clip, hi_x, hi_y, max_ret, fin_count, fin_keys,
                        L.fin_stride, (uint32_t)fin_keys_lds, (float4 *)out_boxes, out_scores, out_labels, out_keep_anchor,
-                       out_count);
+                       out_count, hdr);
     return launch_status("finalize");
 }
 

@@ -450,3 +450,32 @@ def test_tensorflows_own_nms_unit_test_vectors_on_the_gpu():
         assert cpu(keep)[0, :n].tolist() == want, name
         np.testing.assert_array_equal(cpu(b)[0, :n], xyxy[0][want])
         np.testing.assert_array_equal(cpu(s)[0, :n], np.float32(scores)[want])
+
+
+def test_workspace_with_arbitrary_contents():
+    """A call zeroes its own counters inside its first kernel (block 0 of the scan, `ready` = `epoch` + 1 in the
+    workspace's first line): the workspace may hold anything -- zeros, ones, random bytes, the leftovers of a call
+    of another shape -- and a call may follow a call on the same workspace with nothing in between."""
+    rng = np.random.default_rng(31)
+    anchors, regress, scores = _case(rng, 3, 1000, 90, 400)
+    want = c_oracle.decode_nms(anchors, regress, scores, (160, 160), threads=4)
+    other = _case(rng, 2, 2500, 80, 2000)
+    dev = _lib.require_gpu()
+    lib = _lib.load()
+    need = lib.odbox_decode_nms_workspace(3, 1000, 90, 100, 0)
+
+    def ws():
+        return _lib.workspace('decode_nms', dev, need)
+
+    for fill in ('zeros', 'ones', 'random', 'other', 'again', 'again'):
+        if fill == 'zeros':
+            ws().zero_()
+        elif fill == 'ones':
+            ws().fill_(255)
+        elif fill == 'random':
+            w = ws()
+            w.copy_(torch.randint(0, 256, (w.numel(),), dtype=torch.uint8, device=dev))
+        elif fill == 'other':
+            BB.decode_and_nms(other[0], other[1], other[2], (160, 160), return_keep=True)
+        got = BB.decode_and_nms(anchors, regress, scores, (160, 160), return_keep=True)
+        check(got, want)

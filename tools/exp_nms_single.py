@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""One decode+NMS call after the other on the configs[4] share (49 104 anchors, 90 classes, 64 images, pre-NMS top-k
+5 000): HIP-event time per call, median over groups, and a digest of the detections (two builds that print the same
+digest returned the same bits).  The A/B aid for everything behind the score scan.
+
+    python tools/exp_nms_single.py [--iters 20] [--groups 7] [--batch 64]
+"""
+import argparse
+import hashlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from object_detection_amd import _lib, anchors as A, bndbox as BB, workloads  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--groups', type=int, default=7)
+    ap.add_argument('--batch', type=int, default=64)
+    args = ap.parse_args()
+    _lib.load()
+    dev = _lib.require_gpu()
+    c = workloads.CONFIGS[5]
+    anchors = A.generate_anchors(A.AnchorsConfig(), c['S'])
+    N = anchors.shape[0]
+    reg, sc = workloads.nms_inputs(N, C=c['C'], batch=args.batch, p3p4_anchors=9 * (64 * 64 + 32 * 32))
+    reg, sc = torch.as_tensor(reg).to(dev), torch.as_tensor(sc).to(dev)
+
+    def call():
+        return BB.decode_and_nms(anchors, reg, sc, (c['S'], c['S']), pre_nms_topk=5000, return_keep=True)
+    for _ in range(5):
+        out = call()
+    torch.cuda.synchronize()
+    h = hashlib.sha1()
+    for t in out:
+        h.update(t.cpu().numpy().tobytes())
+    times = []
+    for _ in range(args.groups):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1) * 1e3 / args.iters)
+    times.sort()
+    byts = args.batch * workloads.nms_bytes_per_image(N, c['C'])
+    med = times[len(times) // 2]
+    print('%s: per call min %.1f median %.1f max %.1f us  -> %.3f of 8 TB/s   digest %s' % (
+        os.environ.get('ODBOX_LIBRARY', 'default').split('libodbox_')[-1], times[0], med, times[-1], byts / med / 8e6, h.hexdigest()[:12]))
+
+
+if __name__ == '__main__':
+    main()
