@@ -24,10 +24,13 @@ The same JSON line carries
   cpu_baseline        the oracle's C restatement timed on this host's cores on a bounded sample,
   match_loss          SURVEY.md 8f row 1 on the same batch: matcher fused with the focal + Huber loss,
   decode_nms          the inference-side path (configs[4] share: 49 104 anchors, 90 classes, 64 images per GPU,
-                      + one RCCL all-gather of the detections when N > 1).
+                      + one RCCL all-gather of the detections when N > 1): `value` = one call after the other, the
+                      reference's call pattern; `pipelined` = two batches in flight (needs a caller written for it).
+A multi-GPU run (SCALE) reads the top-level `value` (match+encode, no collective) and `decode_nms.value` (with the gather).
 """
 import argparse
 import gc
+import hashlib
 import json
 import os
 import socket
@@ -153,7 +156,7 @@ def timed(fn, steps, warmup, world):
 
 
 def per_step_median(fn, groups=10, per_group=10):
-    """Median (and min) over `groups` of the mean HIP-event time of `per_group` consecutive steps: a
+    """Median (and (min, max)) over `groups` of the mean HIP-event time of `per_group` consecutive steps: a
     single hiccup cannot move the figure, and the event marker between two groups
     (about 2.5 us on the stream) is spread over per_group steps.  Seconds per step."""
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(groups + 1)]
@@ -169,7 +172,7 @@ def per_step_median(fn, groups=10, per_group=10):
     finally:
         gc.enable()
     ts = [ev[g].elapsed_time(ev[g + 1]) * 1e-3 / per_group for g in range(groups)]
-    return statistics.median(ts), min(ts)
+    return statistics.median(ts), (min(ts), max(ts))
 
 
 PLAN_KERNELS = {0: 'match_encode_kernel<false, false>', 1: 'match_encode_kernel<true, false>',
@@ -181,13 +184,20 @@ def match_encode_kernel_name(lib, B, N, G, C):
     return PLAN_KERNELS.get(lib.odbox_match_encode_plan(B, N, G, C, 1, 0), 'match_encode_kernel')
 
 
-def hbm_roofline(kernel, byts, mean_s, median_s, traffic_key=None, **extra):
-    ach = byts / mean_s / 1e9
+def hbm_roofline(kernel, byts, mean_s, median_s, traffic_key=None, spread=None, **extra):
+    """`achieved` / `frac` come from the MEDIAN over groups of steps (per_step_median: 10 groups of 10 by default) --
+    the driver's --steps 20 are 0.9 ms of GPU time for the headline, too short a region for a stable mean -- and the
+    mean over exactly the K timed steps sits beside it (`us_per_launch_timed_steps`, `frac_timed_steps`) with the
+    spread of the group means."""
+    ach = byts / median_s / 1e9
     r = {'bound': 'hbm', 'kernel': kernel, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-         'frac': round(ach / HBM_PEAK_GBS, 4), 'bytes_per_launch': byts, 'us_per_launch': round(mean_s * 1e6, 3),
+         'frac': round(ach / HBM_PEAK_GBS, 4), 'bytes_per_launch': byts, 'us_per_launch': round(median_s * 1e6, 3),
          'us_per_launch_median': round(median_s * 1e6, 3),
-         'frac_median': round(byts / median_s / 1e9 / HBM_PEAK_GBS, 4),
+         'us_per_launch_timed_steps': round(mean_s * 1e6, 3),
+         'frac_timed_steps': round(byts / mean_s / 1e9 / HBM_PEAK_GBS, 4),
          'traffic': load_traffic(traffic_key) if traffic_key else None}
+    if spread:
+        r['us_per_launch_group_min_max'] = [round(spread[0] * 1e6, 3), round(spread[1] * 1e6, 3)]
     if traffic_key:
         r['traffic_source'] = TRAFFIC_SOURCE
     r.update(extra)
@@ -304,16 +314,19 @@ def main():
     lib.odbox_set_output_policy(2)
     k_stream = match_encode_kernel_name(lib, B, N, G, C)
     wall, ev = timed(step, args.steps, args.warmup, world)
-    med, _ = per_step_median(step)
+    med, spr = per_step_median(step)
     img_s = world * B * args.steps / wall
     lib.odbox_set_output_policy(0)
     _, ev0 = timed(step, args.steps, args.warmup, 1)                   # the same rotation under the default policy
-    med0, _ = per_step_median(step)
-    k_auto = PLAN_KERNELS.get(lib.odbox_match_encode_last_plan(), 'match_encode_kernel')      # what AUTO really launched
-    # the same launch rewriting ONE output set every step: its 245 MB fit the Infinity Cache
+    med0, spr0 = per_step_median(step)
+    k_auto = PLAN_KERNELS.get(lib.odbox_match_encode_last_plan(), 'match_encode_kernel')      # what AUTO launched (a function of the shape)
+    # the same launch rewriting ONE output set every step, through the caches (policy 'cache': the caller knows its
+    # buffer is still in the Infinity Cache): its 245 MB fit there
+    lib.odbox_set_output_policy(1)
     _, ev1 = timed(lambda i: step(0), args.steps, args.warmup, 1)
-    med1, _ = per_step_median(lambda i: step(0))
+    med1, spr1 = per_step_median(lambda i: step(0))
     k_resident = PLAN_KERNELS.get(lib.odbox_match_encode_last_plan(), 'match_encode_kernel')
+    lib.odbox_set_output_policy(0)
 
     result = {
         'metric': 'images/sec match+encode (IoU matching + target encoding)',
@@ -335,16 +348,16 @@ def main():
                                % (N, C, G, B, OUTPUT_SETS, OUTPUT_SETS * B * N * (C + 6) * 4 / 1e9),
                    'global_batch': world * B, 'anchors': N, 'classes': C, 'gt_per_image': G,
                    'parallelism': 'images sharded over %d GPU(s), no collective' % world},
-        'roofline': hbm_roofline(k_stream, w['bytes'], ev / args.steps, med, 'match_encode_kernel_rotating',
+        'roofline': hbm_roofline(k_stream, w['bytes'], ev / args.steps, med, 'match_encode_kernel_rotating', spr,
                                  output_sets=OUTPUT_SETS, output_policy='stream'),
         'roofline_auto_policy': hbm_roofline(
-            k_auto, w['bytes'], ev0 / args.steps, med0, None, output_sets=OUTPUT_SETS, output_policy='auto',
-            note='the same rotation under the default policy: what a caller that says nothing about its consumer gets on '
-                 'cold buffers (AUTO sees that no buffer of the rotation was written a moment ago and streams)'),
+            k_auto, w['bytes'], ev0 / args.steps, med0, None, spr0, output_sets=OUTPUT_SETS, output_policy='auto',
+            note='the same rotation under the default policy: what a caller that says nothing about its consumer gets '
+                 '(AUTO is a function of the shape and assumes a cold buffer: the sweep for this shape, on every run)'),
         'roofline_cache_resident': hbm_roofline(
-            k_resident, w['bytes'], ev1 / args.steps, med1, 'match_encode_kernel', output_policy='auto',
-            note='one output set rewritten every step: the 245 MB of stores fit the 256 MB Infinity Cache, so this is '
-                 'a cache-assisted store rate, not an HBM fraction'),
+            k_resident, w['bytes'], ev1 / args.steps, med1, 'match_encode_kernel', spr1, output_policy='cache',
+            note="one output set rewritten every step under policy 'cache': the 245 MB of stores fit the 256 MB "
+                 'Infinity Cache, so this is a cache-assisted store rate, not an HBM fraction'),
     }
     gt_np, lab_np = w['gt_np'], w['lab_np']
     gt, lab = w['gt'], w['lab']
@@ -371,7 +384,7 @@ def main():
             lib.odbox_set_output_policy(2 if sets > 2 else 0)           # rotating (cold) outputs: written around the caches
             k_cfg = match_encode_kernel_name(lib, Bc, wc['N'], wc['G'], wc['C'])
             wl, el = timed(stepc, ksteps, 3, world)
-            medc, _ = per_step_median(stepc, per_group=5)
+            medc, sprc = per_step_median(stepc, per_group=5)
             lib.odbox_set_output_policy(0)
             sub = {'value': round(world * Bc * ksteps / wl, 1), 'unit': 'images/s', 'steps': ksteps,
                    'config': {'workload': label}}
@@ -387,7 +400,7 @@ def main():
                                    'frac_source': 'static: VALU-busy cycles / launch cycles from the SQ counter passes '
                                                   '(tools/pmc_cfg.sh 4, profiles/), not measured in this run'}
             else:
-                sub['roofline'] = hbm_roofline(k_cfg, wc['bytes'], el / ksteps, medc, None, output_sets=sets,
+                sub['roofline'] = hbm_roofline(k_cfg, wc['bytes'], el / ksteps, medc, None, sprc, output_sets=sets,
                                                output_policy='stream' if sets > 2 else 'auto')
             result[key] = sub
             del stepc, wc
@@ -435,14 +448,15 @@ def main():
                                     ('forward_f16', fwd16_step, fixed + B * N * (8 + 2 * C), 'match_loss_kernel_f16_fwd'),
                                     ('backward_f16', bwd16_step, fixed + 2 * B * N * (8 + 2 * C), 'match_loss_kernel_f16_bwd')):
             wl, el = timed(fn, args.loss_steps, 5, world)
-            medl, _ = per_step_median(fn)
+            medl, sprl = per_step_median(fn)
             result['match_loss'][name] = {
                 'value': round(world * B * args.loss_steps / wl, 1), 'unit': 'images/s',
                 'us_per_step': round(el / args.loss_steps * 1e6, 2), 'steps': args.loss_steps,
-                'roofline': hbm_roofline('match_loss_kernel (+ its reduction)', byt, el / args.loss_steps, medl, tkey)}
+                'roofline': hbm_roofline('match_loss_kernel (+ its reduction)', byt, el / args.loss_steps, medl, tkey, sprl)}
         del pb, ps, gb, gs, hb, hs, ghb, ghs
 
     # ---------------- decode + NMS, configs[4] per-GPU share -------------------------------
+    nms_cpu_sample = None
     if not args.no_nms:
         S5, B5, C5 = 512, 64, 90
         anchors5 = A.generate_anchors(A.AnchorsConfig(), S5)
@@ -451,32 +465,42 @@ def main():
                                                p3p4_anchors=9 * (64 * 64 + 32 * 32), distinct=B5)
         reg5 = torch.as_tensor(reg5_np).to(dev)
         sc5 = torch.as_tensor(sc5_np).to(dev)
-        cb5 = None
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            cb5 = cpu_baseline_nms(anchors5.cpu().numpy(), reg5_np, sc5_np, S5)
+            nms_cpu_sample = (anchors5.cpu().numpy(), reg5_np[:16].copy(), sc5_np[:16].copy(), S5)   # timed last
         del reg5_np, sc5_np
         out = {}
 
         def nms_step(i):
+            # what the reference's loop does (evaluate.py:83-85, encoder.py:200-214): one batch after the other
             b, s, l = BB.decode_and_nms(anchors5, reg5, sc5, (S5, S5), pre_nms_topk=5000)
             out['det'] = oddist.gather_detections(b, s, l, batch=None)
 
         wall5, ev5 = timed(nms_step, args.nms_steps, 3, world)
-        med5, _ = per_step_median(nms_step, per_group=4)
+        med5, spr5 = per_step_median(nms_step, per_group=4)
         bytes5 = B5 * workloads.nms_bytes_per_image(N5, C5)
-        single = {
+        digest = hashlib.sha1()
+        for t in out['det']:
+            digest.update(t.cpu().numpy().tobytes())
+        result['decode_nms'] = {
+            'metric': 'images/sec decode+clip+per-class NMS+top-k, one call after the other'
+                      + (' + RCCL all-gather of the detections' if world > 1 else ''),
             'value': round(world * B5 * args.nms_steps / wall5, 1), 'unit': 'images/s',
             'ms_per_step': round(wall5 / args.nms_steps * 1e3, 4), 'steps': args.nms_steps,
-            'roofline': hbm_roofline('whole decode+NMS pipeline (score_scan dominates)', bytes5, ev5 / args.nms_steps, med5,
-                                     'score_scan_kernel'),
-            'note': 'one batch at a time on one stream: the latency of a call; partition / NMS / top-k (55 us) run '
-                    'behind the 178 us score scan with the memory system idle'}
+            'config': {'workload': 'configs[4] per-GPU share: %d anchors, %d classes, batch %d per GPU (%d distinct synthetic '
+                                   'images), score 0.3, IoU 0.45, max_ret 100, pre-NMS top-k 5000 (~4500 candidates/img: it '
+                                   'never binds); the 1.13 GB score tensor is 4x the Infinity Cache; ONE batch at a time '
+                                   'through bndbox.decode_and_nms -- the call pattern of evaluate.py:83-85 -- so `value` is the '
+                                   'drop-in rate; `pipelined` is what a caller that keeps two batches in flight gets'
+                                   % (N5, C5, B5, B5),
+                       'global_batch': world * B5},
+            'roofline': hbm_roofline('whole decode+NMS call: score_scan (HBM-bound), then partition, NMS, final top-k '
+                                     '(latency-bound)', bytes5, ev5 / args.nms_steps, med5, 'score_scan_kernel', spr5,
+                                     frac_scores_only=round(B5 * N5 * C5 * 4 / med5 / 1e9 / HBM_PEAK_GBS, 4)),
+            'detections_per_image_mean': float((out['det'][1] > 0).sum().item()) / (world * B5),
+            'detections_sha1': digest.hexdigest(),
+        }
 
-        if args.no_nms_pipeline:
-            single['metric'] = 'images/sec decode+clip+per-class NMS+top-k, one batch at a time'
-            result['decode_nms'] = single
-            args.no_nms = True
-    if not args.no_nms:
+    if not args.no_nms and not args.no_nms_pipeline:
         # two batches in flight (bndbox.DecodeNmsPipeline): the scan of batch k+1 runs beside the tail of batch k
         pipe = BB.DecodeNmsPipeline(depth=2)
         ksteps = max(args.nms_steps, 2) * 3
@@ -512,27 +536,15 @@ def main():
 
         wall2 = timed_pipeline(pipelined)
         same = all(torch.equal(a, b) for a, b in zip(out['det'], out['det2']))
-        result['decode_nms'] = {
-            'metric': 'images/sec decode+clip+per-class NMS+top-k' + (' + RCCL all-gather' if world > 1 else ''),
+        result['decode_nms']['pipelined'] = {
+            'note': 'TWO batches in flight on two streams (bndbox.DecodeNmsPipeline; no counterpart in the reference, whose '
+                    'loop decodes one batch at a time): needs a caller written around submit() / result(), so it is not '
+                    '`value`',
             'value': round(world * B5 * ksteps / wall2, 1), 'unit': 'images/s',
             'ms_per_step': round(wall2 / ksteps * 1e3, 4), 'steps': ksteps,
-            'config': {'workload': 'configs[4] per-GPU share: %d anchors, %d classes, batch %d per GPU (%d distinct synthetic '
-                                   'images), score 0.3, IoU 0.45, max_ret 100, pre-NMS top-k 5000 (~4500 candidates/img: it never binds); the 1.13 GB score '
-                                   'tensor is 4x the Infinity Cache; TWO batches in flight on two streams '
-                                   '(bndbox.DecodeNmsPipeline), every step a full batch of 64 images through the same '
-                                   'odbox_decode_nms entry point; `single_stream` is one batch at a time' % (N5, C5, B5, B5)},
-            'roofline': {'bound': 'hbm', 'kernel': 'whole decode+NMS pipeline (score_scan dominates)',
-                         'achieved': round(bytes5 / (wall2 / ksteps) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(bytes5 / (wall2 / ksteps) / 1e9 / HBM_PEAK_GBS, 4), 'bytes_per_launch': bytes5,
-                         'us_per_launch': round(wall2 / ksteps * 1e6, 3),
-                         'frac_scores_only': round(B5 * N5 * C5 * 4 / (wall2 / ksteps) / 1e9 / HBM_PEAK_GBS, 4),
-                         'traffic': load_traffic('score_scan_kernel'), 'traffic_source': TRAFFIC_SOURCE,
-                         'timing': 'wall clock, median of 3 runs of %d steps (work is on two streams: no single event '
-                                   'pair brackets it)' % ksteps},
-            'single_stream': single,
-            'pipelined_equals_single_stream': bool(same),
-            'detections_per_image_mean': float((out['det'][1] > 0).sum().item()) / (world * B5),
-        }
+            'frac': round(bytes5 / (wall2 / ksteps) / 1e9 / HBM_PEAK_GBS, 4),
+            'timing': 'wall clock, median of 3 runs of %d steps (work is on two streams: no single event pair brackets it)' % ksteps,
+            'equals_single_calls': bool(same)}
         # the same batch handed over as bfloat16 model outputs (odbox_decode_nms_mixed): half the score bytes, the
         # detections of the widened tensors; reported beside the fp32 figures, never in their place
         sc16, reg16 = sc5.to(torch.bfloat16), reg5.to(torch.bfloat16)
@@ -554,7 +566,7 @@ def main():
                 out['det16'] = oddist.gather_detections(*p.result(), batch=None)
 
         wall16, ev16 = timed(nms16_step, args.nms_steps, 3, world)
-        med16, _ = per_step_median(nms16_step, per_group=4)
+        med16, spr16 = per_step_median(nms16_step, per_group=4)
         wall16p = timed_pipeline(pipelined16)
         want16 = BB.decode_and_nms(anchors5, reg16.float(), sc16.float(), (S5, S5), pre_nms_topk=5000)
         got16 = BB.decode_and_nms(anchors5, reg16, sc16, (S5, S5), pre_nms_topk=5000)
@@ -563,22 +575,23 @@ def main():
                     'widened exactly where they are read; not the reference precision, so not part of `value`',
             'single_stream': {'value': round(world * B5 * args.nms_steps / wall16, 1), 'unit': 'images/s',
                               'ms_per_step': round(wall16 / args.nms_steps * 1e3, 4),
-                              'roofline': hbm_roofline('whole decode+NMS pipeline, 16-bit score scan', bytes16,
-                                                       ev16 / args.nms_steps, med16, None)},
+                              'roofline': hbm_roofline('whole decode+NMS call, 16-bit score scan', bytes16,
+                                                       ev16 / args.nms_steps, med16, None, spr16)},
             'pipelined': {'value': round(world * B5 * ksteps / wall16p, 1), 'unit': 'images/s', 'batches_in_flight': 3,
                           'ms_per_step': round(wall16p / ksteps * 1e3, 4),
                           'frac': round(bytes16 / (wall16p / ksteps) / 1e9 / HBM_PEAK_GBS, 4)},
             'equals_fp32_path_on_widened_inputs': bool(all(torch.equal(a, b) for a, b in zip(got16, want16))),
         }
         del sc16, reg16
-        if cb5 is not None:
-            result['decode_nms']['cpu_baseline'] = {
-                'value': round(cb5['multi'][0], 1), 'unit': 'images/s', 'cores': cb5['multi'][1], 'kind': 'port',
-                'sample': 'oracle/odbox_oracle.c decode + per-class NMS + top-k on the first 16 images of the same '
-                          'batch, repeated to %d images, OpenMP over images' % cb5['multi'][2],
-                'value_1core': round(cb5['single'][0], 1)}
 
-    # ---------------- CPU baseline (rank 0, N = 1 only) ------------------------------------
+    # ---------------- CPU baselines (rank 0, N = 1 only), LAST: everything above is GPU work back to back --------
+    if nms_cpu_sample is not None:
+        cb5 = cpu_baseline_nms(*nms_cpu_sample)
+        result['decode_nms']['cpu_baseline'] = {
+            'value': round(cb5['multi'][0], 1), 'unit': 'images/s', 'cores': cb5['multi'][1], 'kind': 'port',
+            'sample': 'oracle/odbox_oracle.c decode + per-class NMS + top-k on the first 16 images of the same '
+                      'batch, repeated to %d images, OpenMP over images' % cb5['multi'][2],
+            'value_1core': round(cb5['single'][0], 1)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline_match(anchors.cpu().numpy(), gt_np, lab_np, C, S)
         result['cpu_baseline'] = {

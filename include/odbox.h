@@ -26,7 +26,10 @@
 extern "C" {
 #endif
 
-#define ODBOX_VERSION 100            /* 0.1.0 */
+/* 200: the signatures of odbox_match_encode (trailing out_gt_best) and odbox_gt_prepare_xywh / _poly (`rows`) changed
+ * against 100, and the first 256 bytes of the decode+NMS workspace became the library's epoch / ready line.  A caller
+ * built against another header must not call in: compare odbox_version() with ODBOX_VERSION first. */
+#define ODBOX_VERSION 200            /* 0.2.0 */
 #define ODBOX_EINVAL (-1)            /* bad argument (shape, NULL, limit exceeded) */
 #define ODBOX_EHIP   (-2)            /* a HIP runtime call failed */
 #define ODBOX_ENOSPC (-3)            /* workspace too small */
@@ -43,14 +46,17 @@ const char *odbox_last_error(void);
 
 /* How odbox_match_encode writes its dense outputs (no counterpart in the reference: a property of this
  * GPU's memory system).  Through the caches is right when the stores land in lines the 256 MB Infinity Cache
- * still holds (one buffer rewritten call after call) or when the consumer reads the targets next; around
- * them (nontemporal stores) when the buffer is fresh or large.  AUTO (default) decides per call: labels beyond
- * 512 MB go around the caches (GT lists of at most 80 rows); label-stream shapes (those the lockstep sweep serves, see
- * odbox_match_encode_plan) go around them too UNLESS this very buffer was written by a call of the last 5 ms
- * and the bytes the library has written since fit the cache; everything else goes through.  CACHE / STREAM
- * force one or the other -- except that label rows narrower than 64 floats (C < 63) always go through the
- * caches: streamed, their tiles are too small to be worth a block each.  Process-wide; returns the previous policy, or ODBOX_EINVAL.  Results are
- * bit-identical under every policy. */
+ * still holds (one buffer rewritten call after call with nothing in between) or when the consumer reads the
+ * targets next; around them (nontemporal stores) when the buffer is cold or large.  The library cannot see
+ * what passed through the cache since a buffer was last written, so AUTO (default) is a function of the call's
+ * shape alone and assumes a cold buffer: labels beyond 512 MB (GT lists of at most 80 rows) and label-stream
+ * shapes (those the lockstep sweep serves, see odbox_match_encode_plan) go around the caches, everything else
+ * through them.  The same call always launches the same kernel -- also under HIP graph capture -- and
+ * odbox_match_encode_plan tells which.  CACHE / STREAM force one or the other (say CACHE when the consumer
+ * reads the targets straight away or one buffer is rewritten in a tight loop) -- except that label rows
+ * narrower than 64 floats (C < 63) always go through the caches: streamed, their tiles are too small to be
+ * worth a block each.  Process-wide; returns the previous policy, or ODBOX_EINVAL.  Results are bit-identical
+ * under every policy. */
 #define ODBOX_POLICY_AUTO   0
 #define ODBOX_POLICY_CACHE  1
 #define ODBOX_POLICY_STREAM 2
@@ -60,10 +66,9 @@ int odbox_set_output_policy(int policy);
  * policy (no counterpart in the reference; for tests, benchmarks and logs -- the results are the same
  * bits on every plan).  TILES: one block per 256-anchor tile, stores through the caches.  TILES_STREAM:
  * 64-anchor tiles, nontemporal stores.  SWEEP: streamed outputs with wide label rows (C + 1 >= 69), at
- * most 64 GT rows, B <= 8192, 16-byte aligned labels, no per-GT output and at most 768 MB of labels: the label tensor
+ * most 64 GT rows, B <= 8192, B * G <= 20480 or B * G * 20480 <= the label bytes, 16-byte aligned labels, no per-GT output and at most 768 MB of labels: the label tensor
  * is written as one chip-wide lockstep sweep of 4 KB pieces by dedicated store waves while other waves
- * of the same blocks match and patch (the fastest order into cold HBM).  Under AUTO the answer is the one
- * for a buffer that no recent call wrote.  Returns ODBOX_EINVAL on a bad shape.
+ * of the same blocks match and patch (the fastest order into cold HBM).  Returns ODBOX_EINVAL on a bad shape.
  * odbox_match_encode_last_plan: the plan the calling thread's last odbox_match_encode actually took
  * (-1 before the first call). */
 #define ODBOX_PLAN_TILES        0
@@ -124,8 +129,9 @@ int odbox_match_loss(const float *anchors /*[N,4]*/, const float *gt_boxes /*[B,
  * neither size nor own a workspace.  Same arguments, kernels and results as odbox_match_loss, minus
  * the workspace: the per-tile partial sums live in a 1 MiB array in the library's own device memory
  * (one copy per GPU, held until the process ends), whose address is looked up once per device on
- * the first call there (make that first call outside graph capture, with the stream's device
- * current).  Limit: B * ceil(N / 256) <= ODBOX_NOALLOC_MAX_TILES, else ODBOX_ENOSPC.  The call
+ * the first call there (make that first call outside graph capture).  On EVERY call the stream's device
+ * must be the current device (ODBOX_EINVAL otherwise): the kernels run on the stream's GPU with the address
+ * of the current GPU's copy.  Limit: B * ceil(N / 256) <= ODBOX_NOALLOC_MAX_TILES, else ODBOX_ENOSPC.  The call
  * itself allocates nothing.  Every call on one GPU shares that GPU's array: calls that overlap on
  * one GPU (different streams without an ordering between them) race; one stream is always fine. */
 #define ODBOX_NOALLOC_MAX_TILES 65536

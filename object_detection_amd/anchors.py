@@ -90,9 +90,12 @@ _POLICIES = {'auto': 0, 'cache': 1, 'stream': 2}
 
 def set_output_policy(policy: str) -> str:
     """How `anchor_targets_bbox` / `match_encode` write their dense outputs (`odbox_set_output_policy`):
-    'auto' (through the caches up to 512 MB of labels, around them beyond), 'cache', or 'stream' (for
-    targets nothing reads soon, e.g. computed ahead of the training step into a fresh buffer every
-    call).  Same bits either way.  Returns the previous policy."""
+    'auto' (the default; a function of the call's shape alone, which assumes a buffer that is not in the 256 MB
+    Infinity Cache: label tensors beyond 512 MB and the label-stream shapes the lockstep sweep serves -- wide rows,
+    at most 64 GT rows -- go around the caches, everything else through them; `match_encode_plan` tells which kernel a
+    shape gets, and a captured HIP graph holds exactly that one), 'cache' (the consumer reads the targets straight
+    away, or one buffer is rewritten in a tight loop), or 'stream' (targets nothing reads soon).  Same bits either
+    way.  Returns the previous policy."""
     if policy not in _POLICIES:
         raise ValueError("policy must be 'auto', 'cache' or 'stream'")
     prev = _lib.load().odbox_set_output_policy(_POLICIES[policy])

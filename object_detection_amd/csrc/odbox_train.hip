@@ -10,7 +10,6 @@
 // Reference citations are file:line under the reference tree (bioothod/object_detection).
 #include "odbox_common.h"
 #include <atomic>
-#include <chrono>
 #include <mutex>
 #include <type_traits>
 
@@ -558,7 +557,7 @@ __global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE_ENC) void match_e
 //                          element lies IN, once the store waves say that piece's zeros are out -- a row
 //                          that straddles two pieces is matched twice, by the two blocks that own them.
 // Taken by odbox_match_encode for streamed outputs (ODBOX_POLICY_STREAM; AUTO beyond ODBOX_STREAM_MB or for a buffer
-// that is not still in the Infinity Cache, see recently_written)
+// that may not be in the Infinity Cache any more, see ODBOX_POLICY_AUTO)
 // with wide label rows (C + 1 >= 69: at most 16 rows per piece), G <= 64, 16-byte aligned labels of at most
 // ODBOX_SWEEP_MAX_MB and no per-GT output; everything else stays with match_encode_kernel.
 // ------------------------------------------------------------------------------------------
@@ -1415,57 +1414,27 @@ int train_cu_count()
     return cached_cus;
 }
 
-// ---- ODBOX_POLICY_AUTO: is the label buffer of this call still in the Infinity Cache? --------------------------
+// ---- ODBOX_POLICY_AUTO is a function of the call's shape, nothing else (round 3) ------------------------------
 // Through the caches a launch is 1.2x faster when its stores land in lines the 256 MB Infinity Cache still holds (one
-// buffer rewritten call after call: configs[1] 33.5 us against 40 us around the caches) and 1.25x SLOWER when they do
-// not (a fresh or rotating buffer: 49.6 against 39.5 us; same-box table in profiles/README.md, tools/exp_policy.py).
-// The library sees every dense output it writes, so AUTO keeps the last few (pointer, bytes, time) per device, most
-// recent first, and calls a buffer resident when it was written a moment ago and the bytes written since -- its own
-// included -- fit the cache: the reuse distance of an LRU cache.  The time bound stands for everything the library
-// does NOT see: a training step between two calls streams gigabytes through the cache, and at 6 TB/s 256 MB last 40 us.
-constexpr uint64_t MALL_BYTES = 256ull << 20;
-constexpr int RECENT_OUTS = 16;
-constexpr std::chrono::microseconds RECENT_WINDOW{5000};
-struct RecentOut {
-    const void *ptr;
-    uint64_t bytes;
-    int dev;
-    std::chrono::steady_clock::time_point when;
-};
-std::mutex g_recent_mu;
-RecentOut g_recent[RECENT_OUTS];
-int g_recent_n = 0;
-
-bool recently_written(const void *ptr, uint64_t bytes)
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    const auto now = std::chrono::steady_clock::now();
-    std::lock_guard<std::mutex> lock(g_recent_mu);
-    uint64_t distance = bytes;
-    bool resident = false;
-    int at = g_recent_n < RECENT_OUTS ? g_recent_n : RECENT_OUTS - 1;      // slot that is dropped (or the new one)
-    for (int i = 0; i < g_recent_n; ++i) {
-        if (g_recent[i].dev != dev) continue;
-        if (g_recent[i].ptr == ptr) {
-            resident = g_recent[i].bytes == bytes && distance <= MALL_BYTES && now - g_recent[i].when <= RECENT_WINDOW;
-            at = i;
-            break;
-        }
-        distance += g_recent[i].bytes;
-    }
-    if (at == g_recent_n) ++g_recent_n;
-    for (int i = at; i > 0; --i) g_recent[i] = g_recent[i - 1];
-    g_recent[0] = RecentOut{ptr, bytes, dev, now};
-    return resident;
-}
-
+// buffer rewritten call after call with nothing in between: configs[1] 33.5 us against 40 us around the caches) and
+// 1.25x SLOWER when they do not (a fresh or rotating buffer, or one that a training step's gigabytes have pushed out
+// since: 49.6 against 39.5 us; same-box table in profiles/README.md, tools/exp_policy.py).  Whether the lines are still
+// there depends on traffic the library cannot see.  Round 2 guessed from a host clock (5 ms) and a list of its own
+// recent outputs; that made the kernel of a call depend on host jitter, froze a guess into captured HIP graphs and took
+// a process-wide mutex per call.  Now AUTO assumes what holds in every real loop -- the buffer is cold -- and takes the
+// sweep wherever it applies; a caller whose consumer reads the targets straight away, or who rewrites one buffer in a
+// tight loop, says ODBOX_POLICY_CACHE.  No state, no clock, no lock: the same call always launches the same kernel, and
+// odbox_match_encode_plan tells which.
 thread_local int g_last_plan = -1;      // odbox_match_encode_last_plan
 
 // does a streamed launch of odbox_match_encode take match_encode_sweep_kernel?
 bool sweep_applies(uint64_t label_bytes, int B, int G, uint32_t d, bool labels_aligned16, bool gt_best)
 {
+    // (staging: every one of the 512 blocks looks at the whole batch's GT rows once, 20 bytes each; those reads -- out
+    // of L2 after the first block -- must stay under half the bytes the launch writes, or the tiles are the better plan:
+    // B = 8192, G = 64, N = 100 would read 5 GB to write 265 MB; up to 20 480 rows -- 400 KB per block -- nobody counts)
     bool sweep = label_bytes > 0 && !gt_best && labels_aligned16 && G <= SWEEP_MAX_G && B <= SWEEP_MAX_B &&
+                 ((uint64_t)B * (uint64_t)G <= 20480ull || (uint64_t)B * (uint64_t)G * 20ull * 512ull * 2ull <= label_bytes) &&
                  (SWEEP_PIECE + d - 1u) / d + 1u <= (uint32_t)SWEEP_RPP &&
                  label_bytes / sizeof(float) <= 0xffffffffull - 4u * SWEEP_PIECE &&
                  label_bytes <= ((uint64_t)(train_tuning_env("ODBOX_SWEEP_MAX_MB") ? atoi(train_tuning_env("ODBOX_SWEEP_MAX_MB")) : ODBOX_SWEEP_MAX_MB) << 20);
@@ -1540,12 +1509,10 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
     // C = 20 111 / 111 us around the caches against 63 / 51 us through them, C = 40 62 / 62 against 55 / 36 us
     // (tools/exp_policy_narrow.py); from C + 1 = 64 floats per row the stream wins (C = 80: 43 against 49.5 us cold)
     stream_out = stream_out && d >= (uint32_t)STREAM_MIN_ROW;
-    // AUTO below the size rule, for the shapes the sweep serves (a label stream with a cheap match): around the caches
-    // unless this very buffer was written a moment ago and is still in the Infinity Cache (recently_written)
-    if (policy == ODBOX_POLICY_AUTO && !stream_out && sweep_applies(label_bytes, B, G, d, aligned16(out_labels), out_gt_best != nullptr)) {
-        const uint64_t out_bytes = label_bytes + (out_regression ? (uint64_t)B * (uint64_t)N * 5u * sizeof(float) : 0u);
-        stream_out = !recently_written(out_labels, out_bytes);
-    }
+    // AUTO below the size rule, for the shapes the sweep serves (a label stream with a cheap match): around the caches,
+    // as for a buffer that is not in the Infinity Cache (see above: the library cannot know, and cold is the usual case)
+    if (policy == ODBOX_POLICY_AUTO && !stream_out && sweep_applies(label_bytes, B, G, d, aligned16(out_labels), out_gt_best != nullptr))
+        stream_out = true;
 #ifdef ODBOX_ENC_REMAP_FORCE
     const uint32_t remap = ODBOX_ENC_REMAP_FORCE;
 #else
@@ -1807,11 +1774,19 @@ std::mutex g_scratch_mu;
 float *g_scratch_ptr[MAX_DEVICES];                        // device address of `scratch`, per GPU
 
 // The current device's copy of `scratch` (set-up on the first call on that device).
-int scratch_on_current_device(const char *name, float **out)
+// The kernels run on the STREAM's device with the address looked up here, so the two must be the same GPU on every
+// call (another GPU's copy would be a peer access at best, and two GPUs sharing one array race).
+int scratch_on_current_device(const char *name, void *stream, float **out)
 {
     int dev = -1;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= MAX_DEVICES) return fail(ODBOX_EINVAL, "%s: device ordinal %d out of range", name, dev);
+    if (stream) {
+        hipDevice_t sdev = dev;
+        if (hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess && (int)sdev != dev)
+            return fail(ODBOX_EINVAL, "%s: the stream belongs to device %d but the current device is %d: make the stream's "
+                        "device current for the call", name, (int)sdev, dev);
+    }
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     if (!g_scratch_ptr[dev]) {
         float *p = nullptr;
@@ -1838,7 +1813,7 @@ int odbox_match_loss_noalloc(const float *anchors, const float *gt_boxes, const 
         return fail(ODBOX_ENOSPC, "%s: B * ceil(N / %d) = %llu tiles, the library-owned scratch holds %u; use "
                     "odbox_match_loss with a caller workspace", name, ME_TILE, (unsigned long long)tiles, NOALLOC_MAX_TILES);
     float *ws = nullptr;
-    if (int rc = scratch_on_current_device(name, &ws)) return rc;
+    if (int rc = scratch_on_current_device(name, stream, &ws)) return rc;
     return match_loss_run<float>(name, anchors, gt_boxes, gt_labels, B, N, G, C, img_h, img_w, neg_thr, pos_thr, pred_boxes,
                                  pred_scores, gamma, alpha, huber_delta, out_loss, GradScale{nullptr, nullptr, nullptr, 0},
                                  grad_boxes, grad_scores, ws, sizeof(float) * 4 * NOALLOC_MAX_TILES, stream);

@@ -78,6 +78,20 @@ def unpack_detections(records):
     return boxes, scores, labels
 
 
+def _rehearsal_gather_through_host(rec, world, group):
+    """Device records on a gloo group: gloo moves host memory only.  This exists for ONE purpose, rehearsing the
+    N > 1 path where RCCL has no peers (several ranks on one GPU: tests/test_zy_gpu_dist2.py, tests/test_zz_gpu_bench2.py),
+    and only runs when the process says so with ODBOX_DIST_BACKEND=gloo -- the same switch that makes init_from_env
+    open a gloo group.  Anywhere else it is an error: a real run must never fall into a blocking host copy."""
+    if os.environ.get('ODBOX_DIST_BACKEND') != 'gloo':
+        from . import _lib
+        raise _lib.OdboxError('gather_detections: device tensors on a gloo process group; use the "nccl" backend (RCCL), '
+                              'or set ODBOX_DIST_BACKEND=gloo for the host-staged rehearsal on a machine without peers')
+    host = torch.empty((world * rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype)
+    dist.all_gather_into_tensor(host, rec.cpu(), group=group)
+    return host.to(rec.device)
+
+
 def gather_detections(boxes, scores, labels, batch=None, group=None, always=False):
     """All ranks pass the detections of their shard ([b,R,4], [b,R], [b,R] with b =
     ceil(batch / world), short shards zero-padded here) and get the whole batch back, images in
@@ -92,12 +106,9 @@ def gather_detections(boxes, scores, labels, batch=None, group=None, always=Fals
     per = None if batch is None else (batch + world - 1) // world
     rec = pack_detections(boxes, scores, labels, rows=per)
     if rec.is_cuda and dist.get_backend(group) == 'gloo':
-        # rehearsal of the N > 1 path on a machine without RCCL peers (tests/test_zy_gpu_dist2.py: two ranks
-        # on one GPU): gloo moves host memory, so the records are staged through it
-        host = torch.empty((world * rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype)
-        dist.all_gather_into_tensor(host, rec.cpu(), group=group)
-        out = host.to(rec.device)
+        out = _rehearsal_gather_through_host(rec, world, group)
     else:
+        # the product path: device records, one collective (RCCL when the backend is "nccl"), no host copy
         out = torch.empty((world * rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
         dist.all_gather_into_tensor(out, rec, group=group)
     if batch is not None:

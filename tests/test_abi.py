@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.odbox_version() == 100
+    assert lib.odbox_version() == 200
     assert isinstance(lib.odbox_last_error(), bytes)
 
 
@@ -208,7 +208,7 @@ def test_every_entry_rejects_bad_arguments_without_touching_the_gpu(lib):
     assert lib.odbox_set_output_policy(7) == -1 and b'odbox_set_output_policy' in lib.odbox_last_error()
     assert lib.odbox_set_output_policy(2) == 0 and lib.odbox_set_output_policy(0) == 2
     # which kernel a dense match+encode takes is host logic (odbox_match_encode_plan: 0 tiles, 1 streamed tiles, 2 sweep)
-    assert lib.odbox_match_encode_plan(64, 10647, 20, 80, 1, 0) == 2               # AUTO, a label-stream shape, a buffer no recent call wrote
+    assert lib.odbox_match_encode_plan(64, 10647, 20, 80, 1, 0) == 2               # AUTO, a label-stream shape: the sweep (AUTO is a function of the shape)
     assert lib.odbox_match_encode_plan(64, 10647, 20, 80, 0, 0) == 0 and lib.odbox_match_encode_plan(64, 10647, 65, 80, 1, 0) == 0
     assert lib.odbox_match_encode_last_plan() == -1                                # no call yet on this thread
     assert lib.odbox_match_encode_plan(160, 10647, 20, 80, 1, 0) == 2              # 552 MB: streamed, wide rows, short GT list
@@ -221,6 +221,7 @@ def test_every_entry_rejects_bad_arguments_without_touching_the_gpu(lib):
     assert lib.odbox_match_encode_plan(128, 49104, 500, 1, 1, 0) == 0              # narrow label rows never stream
     assert lib.odbox_match_encode_plan(600, 10647, 20, 20, 1, 0) == 0 and lib.odbox_match_encode_plan(600, 10647, 20, 63, 1, 0) == 1
     assert lib.odbox_match_encode_plan(8192, 300, 3, 80, 1, 0) == 2 and lib.odbox_match_encode_plan(8193, 300, 3, 80, 1, 0) == 1
+    assert lib.odbox_match_encode_plan(8192, 100, 64, 80, 1, 0) == 1               # staging the batch's GT rows per block would cost more than the labels
     assert lib.odbox_set_output_policy(0) == 2
     assert lib.odbox_match_encode_plan(0, 1, 1, 1, 1, 0) == -1 and b'odbox_match_encode_plan' in lib.odbox_last_error()
     # empty problems are successes, decided before any pointer is looked at

@@ -271,10 +271,11 @@ def test_repeated_calls_into_dirty_buffers(stream_policy):
         np.testing.assert_array_equal(cpu(reg_out)[..., 4], ref['regression'][..., 4])
 
 
-def test_auto_policy_follows_the_reuse_distance_of_the_buffer():
-    """ODBOX_POLICY_AUTO: a label buffer goes through the caches only when this very buffer was written a moment ago
-    and the bytes written since fit the 256 MB Infinity Cache; fresh, rotating or long-untouched buffers take the
-    sweep.  The bits are the same either way."""
+def test_auto_policy_is_a_function_of_the_shape_alone():
+    """AUTO (the default) keeps no state: the same call launches the same kernel whether its buffer is fresh, was
+    written a moment ago, in a rotation or long ago -- the sweep wherever it applies, as for a cold buffer -- and
+    odbox_match_encode_plan says which beforehand.  'cache' is how a caller asks for the other one.  The bits are the
+    same either way."""
     import time
     lib = _lib.load()
     dev = torch.device('cuda')
@@ -283,8 +284,8 @@ def test_auto_policy_follows_the_reuse_distance_of_the_buffer():
     N, C, B = anchors.shape[0], 80, 24                                  # 83 MB of labels per buffer
     gt, lab = workloads.match_inputs(2, batch=B)
     a, g_, l_ = (torch.as_tensor(x).to(dev) for x in (anchors, gt, lab))
-    bufs = [torch.empty((B, N, C + 1), device=dev) for _ in range(4)]
-    regs = [torch.empty((B, N, 5), device=dev) for _ in range(4)]
+    bufs = [torch.empty((B, N, C + 1), device=dev) for _ in range(3)]
+    regs = [torch.empty((B, N, 5), device=dev) for _ in range(3)]
 
     def call(k):
         rc = lib.odbox_match_encode(a.data_ptr(), g_.data_ptr(), l_.data_ptr(), B, N, gt.shape[1], C, 416.0, 416.0, 0.4, 0.5,
@@ -292,28 +293,20 @@ def test_auto_policy_follows_the_reuse_distance_of_the_buffer():
         assert rc == 0, lib.odbox_last_error()
         return A.match_encode_last_plan()
 
-    def soon(ks, want, tries=4):
-        # the rule has a 5 ms clock in it: a host that stalls between two calls only ever turns 'tiles' into 'sweep',
-        # so a 'tiles' expectation gets a few tries and a 'sweep' expectation none
-        for _ in range(tries):
-            if [call(k) for k in ks] == [want] * len(ks):
-                return True
-        return False
-
-    assert call(0) == 'sweep'                                           # never seen
-    assert soon((0, 0, 0), 'tiles')                                     # rewritten in place: still in the cache
-    assert call(1) == 'sweep'
-    call(0)
-    assert soon((1, 0, 1, 0), 'tiles')                                  # two buffers, 2 x 88 MB: both stay resident
-    assert [call(k) for k in (2, 3)] == ['sweep'] * 2
-    assert [call(k) for k in (1, 0, 2, 3)] == ['sweep'] * 4             # four in rotation, oldest first: 352 MB between two writes of one
+    assert A.match_encode_plan(B, N, gt.shape[1], C) == 'sweep'
+    assert [call(k) for k in (0, 0, 0, 1, 0, 1, 2, 2)] == ['sweep'] * 8  # fresh, in place, in rotation: one answer
     torch.cuda.synchronize()
     time.sleep(0.02)
-    assert call(3) == 'sweep'                                           # written last, but 20 ms ago
-    assert soon((3,), 'tiles')
+    assert call(2) == 'sweep'
+    assert A.match_encode_plan(B, N, 65, C) == 'tiles'                  # a shape the sweep does not serve, below the size rule
+    prev = A.set_output_policy('cache')
+    try:
+        assert A.match_encode_plan(B, N, gt.shape[1], C) == 'tiles' and call(1) == 'tiles'
+    finally:
+        A.set_output_policy(prev)
     torch.cuda.synchronize()
     ref = c_oracle.match_encode(anchors, (416, 416), gt, lab, C, threads=8)
-    for k in range(4):
+    for k in range(3):
         np.testing.assert_array_equal(cpu(bufs[k]), ref['labels'])
         np.testing.assert_array_equal(cpu(regs[k])[..., 4], ref['regression'][..., 4])
 
@@ -345,14 +338,26 @@ def test_padding_layouts_and_rows_beyond_the_lds_share(stream_policy):
         check(anchors, (112, 80), gt, lab, C)
 
 
-def test_sweep_replays_from_a_hip_graph(stream_policy):
+@pytest.mark.parametrize('policy', ['stream', 'auto'])
+def test_sweep_replays_from_a_hip_graph(policy):
     """The sweep allocates nothing and reads everything it decides on from device memory (the per-image bounds are
-    recomputed by every launch): captured once, replayed on batches with other boxes and other amounts of padding."""
+    recomputed by every launch): captured once, replayed on batches with other boxes and other amounts of padding.
+    Under the default policy too: AUTO is a function of the shape, so the captured kernel is the one
+    `match_encode_plan` names, not a guess frozen at capture time."""
+    prev = A.set_output_policy(policy)
+    try:
+        _sweep_graph_case()
+    finally:
+        A.set_output_policy(prev)
+
+
+def _sweep_graph_case():
     lib = _lib.load()
     dev = torch.device('cuda')
     anchors_np = O.generate_anchors(256)
     N, C, B, G = anchors_np.shape[0], 80, 5, 64
     anchors = torch.as_tensor(anchors_np).to(dev)
+    assert A.match_encode_plan(B, N, G, C) == 'sweep'                     # what the capture below will hold
 
     def inputs(seed, valid):
         r = np.random.default_rng(seed)

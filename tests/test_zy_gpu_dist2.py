@@ -25,11 +25,11 @@ def _inputs(B):
 
 def _worker(rank, world, port, B, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK='0')
+                      LOCAL_RANK='0', ODBOX_DIST_BACKEND='gloo')       # the rehearsal switch: gloo group, host-staged records
     import torch.distributed as dist
     from object_detection_amd import dist as oddist
     try:
-        oddist.init_from_env(backend='gloo')
+        oddist.init_from_env()
         anchors, reg, sc = _inputs(B)
         b, s, l = oddist.sharded_decode_and_nms(anchors, torch.as_tensor(reg).cuda(), torch.as_tensor(sc).cuda(), (S, S))
         q.put((rank, b.cpu().numpy(), s.cpu().numpy(), l.cpu().numpy()))
