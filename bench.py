@@ -392,13 +392,38 @@ def main():
                 # VALU-bound: 500 GT rows per anchor.  The kernel proves most pairs zero without
                 # evaluating them, so "pairs / peak rate" is not a fraction of anything; the defensible figure is
                 # how busy the VALUs are over the launch (SQ counters, collected in their own PMC passes).
-                sub['roofline'] = {'bound': 'valu', 'kernel': k_cfg, 'us_per_launch': round(el / ksteps * 1e6, 2),
+                # `frac`: the matcher's EVALUATED work against the FMA-free fp32 VALU rate, from this run's time.
+                # Pairs per launch are a constant of the seeded workload (tools/count_pairs.py, a counting build);
+                # 27.25 issue slots per pair is the four-row loop's disassembly (93 full-rate VALU instructions + 4
+                # quarter-rate v_rcp_f32 per four rows).  39.3 T lane-ops/s = 256 CUs x 64 lanes x 2.4 GHz (no FMA: the
+                # path may not contract); the packed ceiling is twice that.  SURVEY.md 8d's nominal figure (every one of
+                # the 3.1 G pairs at 16 ops) exceeds 1 because nine pairs in ten are proven zero, not evaluated.
+                pairs = load_static('match_encode_cfg3_pairs') or {}
+                t_med = medc
+                peak = 256 * 64 * 2.4e9
+                ev_slots = pairs.get('pairs_evaluated_per_launch', 0) * pairs.get('valu_slots_per_pair', 0.0)
+                cull_slots = pairs.get('cull_steps_per_launch', 0) * 64 * pairs.get('valu_slots_per_cull_step', 0)
+                nominal = Bc * wc['N'] * wc['G'] * 16
+                sub['roofline'] = {'bound': 'valu', 'kernel': k_cfg, 'us_per_launch': round(medc * 1e6, 2),
                                    'us_per_launch_median': round(medc * 1e6, 2),
+                                   'us_per_launch_timed_steps': round(el / ksteps * 1e6, 2),
+                                   'us_per_launch_group_min_max': [round(sprc[0] * 1e6, 2), round(sprc[1] * 1e6, 2)],
                                    'bytes_per_launch': wc['bytes'],
-                                   'hbm_frac': round(wc['bytes'] / (el / ksteps) / 1e9 / HBM_PEAK_GBS, 4),
-                                   'frac': load_static('match_encode_cfg3_valu_busy'),
-                                   'frac_source': 'static: VALU-busy cycles / launch cycles from the SQ counter passes '
-                                                  '(tools/pmc_cfg.sh 4, profiles/), not measured in this run'}
+                                   'hbm_frac': round(wc['bytes'] / t_med / 1e9 / HBM_PEAK_GBS, 4),
+                                   'unit': 'T lane-ops/s', 'peak': round(peak / 1e12, 1),
+                                   'achieved': round(ev_slots / t_med / 1e12, 2) if ev_slots else None,
+                                   'frac': round(ev_slots / t_med / peak, 4) if ev_slots else None,
+                                   'frac_with_work_list_build': round((ev_slots + cull_slots) / t_med / peak, 4) if ev_slots else None,
+                                   'pairs_evaluated_per_launch': pairs.get('pairs_evaluated_per_launch'),
+                                   'pairs_evaluated_share': round(pairs.get('pairs_evaluated_per_launch', 0) / (Bc * wc['N'] * wc['G']), 4),
+                                   'pairs_source': 'static: ' + str(pairs.get('source')),
+                                   'nominal_frac_39T': round(nominal / t_med / peak, 3),
+                                   'nominal_frac_79T_packed': round(nominal / t_med / (2 * peak), 3),
+                                   'nominal_note': 'SURVEY.md 8d: B x N x G x 16 ops over the launch time; above 1 because the '
+                                                   'matcher proves most pairs zero without evaluating them (exact, tested)',
+                                   'valu_busy_static': load_static('match_encode_cfg3_valu_busy'),
+                                   'valu_busy_source': 'static: VALU-busy cycles / launch cycles from the SQ counter passes '
+                                                       '(tools/pmc_cfg.sh 4, profiles/), not measured in this run and not `frac`'}
             else:
                 sub['roofline'] = hbm_roofline(k_cfg, wc['bytes'], el / ksteps, medc, None, sprc, output_sets=sets,
                                                output_policy='stream' if sets > 2 else 'auto')

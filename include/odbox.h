@@ -211,6 +211,14 @@ int odbox_focal_loss(const float *y_true /*[n]*/, const float *y_pred /*[n]*/, s
                      float *out /*[4]*/, float *grad /*[n] or NULL*/, void *workspace, size_t workspace_bytes,
                      void *stream);
 
+/* metric.py:9-38 focal_loss row by row, for the two forms the summed entry point above leaves out: from_logits = 1
+ * (metric.py:19-20: tf.nn.softmax over the last axis first) and the un-reduced return (metric.py:33-38 with any
+ * reduction other than 'sum' / 'mean': one sum over the class axis per row).  y_true / y_pred [rows, C];
+ * out_rows [rows]; grad [rows, C] or NULL: d out_rows[row] / d y_pred (through the softmax when from_logits). */
+int odbox_focal_loss_rows(const float *y_true /*[rows,C]*/, const float *y_pred /*[rows,C]*/, size_t rows, int C,
+                          float gamma, float alpha, int from_logits, float *out_rows /*[rows]*/,
+                          float *grad /*[rows,C] or NULL*/, void *stream);
+
 /* bndbox.py:254-299 bbox_overlap: dense [B,N,G] IoU, -1 for padded GT rows.
  * anchors_batched != 0: anchors is [B,N,4]; else [N,4] shared by every image. */
 int odbox_bbox_overlap(const float *anchors, const float *gt_boxes /*[B,G,4]*/, int B, int N, int G,

@@ -162,6 +162,13 @@ __device__ __forceinline__ unsigned long long gbest_key(float v, uint32_t n)
     return ((unsigned long long)f32_ordered(v) << 32) | (0xffffffffu - n);
 }
 
+// Diagnostic builds only (-DODBOX_COUNT_PAIRS, tools/count_pairs.py): how many (anchor, GT row) pairs the matcher
+// really evaluates -- [0] pairs of live lanes in the work lists, [1] 64-row culling steps, [2] waves -- which is what
+// the VALU roofline of the dense-crowd configuration is priced on (bench.py, match_encode_cfg3).
+#ifdef ODBOX_COUNT_PAIRS
+__device__ unsigned long long g_pair_count[4];
+#endif
+
 template <int TILE, bool REDUCE_LATE, bool GTBEST = false, typename EarlyWork>
 __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ anchors,
                                                 const float4 *__restrict__ gt_boxes,
@@ -254,6 +261,14 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
             if (first_zero < 0 && mz != 0ull) first_zero = g0 + gs + __ffsll((unsigned long long)mz) - 1;
             if (first_pad < 0 && mp != 0ull) first_pad = g0 + gs + __ffsll((unsigned long long)mp) - 1;
         }
+#ifdef ODBOX_COUNT_PAIRS
+        const unsigned long long live_lanes = (unsigned long long)__popcll(__ballot(live));
+        if (lane == 0) {
+            atomicAdd(&g_pair_count[0], (unsigned long long)nlist * live_lanes);
+            atomicAdd(&g_pair_count[1], (unsigned long long)((cnt + WAVE - 1) / WAVE));
+            if (g0 == 0) atomicAdd(&g_pair_count[2], 1ull);
+        }
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1247,6 +1262,56 @@ __global__ __launch_bounds__(256) void focal_dense_kernel(const float *__restric
     }
 }
 
+// metric.py:9-38 row by row: the softmax branch (from_logits, :19-20: tf.nn.softmax over the last axis = exp(x - max) /
+// sum) and the un-reduced return (:33-38: one sum over the class axis per row).  One wave per row; the row is re-read
+// per pass out of L2 (this serves the whole-image head, [B, num_image_classes]: kilobytes).  grad (optional): d
+// out_rows[row] / d y_pred -- through the softmax when from_logits: p_i (g_i - sum_j g_j p_j), g = the gradient w.r.t.
+// the clipped probabilities.
+template <bool G15>
+__global__ __launch_bounds__(256) void focal_rows_kernel(const float *__restrict__ y_true, const float *__restrict__ y_pred,
+                                                         uint32_t rows, uint32_t C, LossParams lp, int from_logits,
+                                                         float *__restrict__ out_rows, float *__restrict__ grad)
+{
+    const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (row >= rows) return;
+    const float *yt = y_true + (size_t)row * C, *yp = y_pred + (size_t)row * C;
+    auto wave_sum = [](float x) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        return x;
+    };
+    float mx = 0.0f, den = 1.0f;
+    if (from_logits) {
+        float m = -INFINITY;
+        for (uint32_t c = lane; c < C; c += WAVE) m = fmaxf(m, yp[c]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        float e = 0.0f;
+        for (uint32_t c = lane; c < C; c += WAVE) e += expf(yp[c] - m);
+        mx = m;
+        den = wave_sum(e);
+    }
+    auto prob = [&](uint32_t c) { return from_logits ? expf(yp[c] - mx) / den : yp[c]; };
+    float acc = 0.0f, dot = 0.0f;
+    for (uint32_t c = lane; c < C; c += WAVE) {
+        const float p = prob(c);
+        float g = 0.0f;
+        acc += focal_term<G15, true>(p, yt[c] == 1.0f, lp, g);
+        dot += g * p;
+    }
+    acc = wave_sum(acc);
+    dot = wave_sum(dot);
+    if (lane == 0) out_rows[row] = acc;
+    if (grad) {
+        for (uint32_t c = lane; c < C; c += WAVE) {
+            const float p = prob(c);
+            float g = 0.0f;
+            focal_term<G15, true>(p, yt[c] == 1.0f, lp, g);
+            grad[(size_t)row * C + c] = from_logits ? p * (g - dot) : g;
+        }
+    }
+}
+
 // partials [nblocks, 4] (class_sum, dist_sum, npos, hits) -> out[0] = dist_loss, out[1] = class_loss
 // (both divided by npos when npos != 0, metric.py:121-123), out[2] = npos, out[3] = hits (foreground
 // anchors whose top predicted class is the matched one); sums in double, fixed order.
@@ -1607,6 +1672,19 @@ int odbox_match_encode_plan(int B, int N, int G, int C, int labels_aligned16, in
 
 int odbox_match_encode_last_plan(void) { return g_last_plan; }
 
+#ifdef ODBOX_COUNT_PAIRS
+int odbox_debug_pair_count(unsigned long long *out4, int reset)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_pair_count), sizeof(g_pair_count)));
+    if (reset) {
+        static const unsigned long long zero[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_pair_count), zero, sizeof(zero)));
+    }
+    return 0;
+}
+#endif
+
 size_t odbox_match_loss_workspace(int B, int N)
 {
     if (B < 1 || N < 1) return 0;
@@ -1852,6 +1930,24 @@ int odbox_focal_loss(const float *y_true, const float *y_pred, size_t n, float g
     // sum comes out in out[1]; out_sum must therefore have room for 4 floats
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, st, (const float4 *)workspace, (uint32_t)blocks, out_sum);
     return launch_status("loss_reduce");
+}
+
+int odbox_focal_loss_rows(const float *y_true, const float *y_pred, size_t rows, int C, float gamma, float alpha,
+                          int from_logits, float *out_rows, float *grad, void *stream)
+{
+    if (C < 1) return fail(ODBOX_EINVAL, "odbox_focal_loss_rows: C=%d", C);
+    if (rows == 0) return 0;
+    if (!y_true || !y_pred || !out_rows) return fail(ODBOX_EINVAL, "odbox_focal_loss_rows: NULL pointer");
+    if (rows > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_focal_loss_rows: too many rows");
+    const LossParams lp = {gamma, alpha, 1.0f};
+    const dim3 grid((uint32_t)((rows + 3) / 4));
+    if (gamma == 1.5f)
+        hipLaunchKernelGGL(focal_rows_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, y_true, y_pred, (uint32_t)rows,
+                           (uint32_t)C, lp, from_logits, out_rows, grad);
+    else
+        hipLaunchKernelGGL(focal_rows_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, y_true, y_pred, (uint32_t)rows,
+                           (uint32_t)C, lp, from_logits, out_rows, grad);
+    return launch_status("focal_rows");
 }
 
 int odbox_bbox_overlap(const float *anchors, const float *gt_boxes, int B, int N, int G, int anchors_batched,

@@ -46,21 +46,60 @@ class _FocalLossFn(torch.autograd.Function):
         return grad * g, None, None, None
 
 
+def _focal_rows_launch(lib, y_true, y_pred, gamma, alpha, from_logits, want_grad):
+    C = int(y_pred.shape[-1]) if y_pred.dim() else 1
+    rows = y_pred.numel() // max(C, 1)
+    out = torch.empty(y_pred.shape[:-1] if y_pred.dim() else (), dtype=torch.float32, device=y_pred.device)
+    grad = torch.empty_like(y_pred) if want_grad else None
+    _lib.check(lib.odbox_focal_loss_rows(_lib.ptr(y_true), _lib.ptr(y_pred), rows, C, float(gamma), float(alpha),
+                                         int(bool(from_logits)), _lib.ptr(out), _lib.ptr(grad), _lib.stream_ptr()),
+               'odbox_focal_loss_rows')
+    return out, grad
+
+
+class _FocalRowsFn(torch.autograd.Function):
+    """Per-row focal loss (`odbox_focal_loss_rows`), differentiable w.r.t. y_pred -- through the softmax when
+    from_logits -- with the gradient written by the forward launch."""
+
+    @staticmethod
+    def forward(ctx, y_pred, y_true, gamma, alpha, from_logits):
+        rows, grad = _focal_rows_launch(_lib.load(), y_true, y_pred, gamma, alpha, from_logits, True)
+        ctx.save_for_backward(grad)
+        return rows
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g.unsqueeze(-1), None, None, None, None
+
+
 def focal_loss(y_true, y_pred, gamma: float = 1.5, alpha: float = 0.25, from_logits: bool = False,
                reduction: str = 'sum', return_grad: bool = False):
-    """metric.py:9-38 on dense targets.  reduction 'sum' (default, the only one the reference
-    uses) or 'mean' (mean of the per-row sums).  Differentiable w.r.t. y_pred when it requires
-    grad; return_grad=True instead returns d loss / d y_pred explicitly."""
-    if from_logits:
-        raise NotImplementedError('the reference never calls focal_loss with from_logits=True')
-    if reduction not in ('sum', 'mean'):
-        raise NotImplementedError("reduction must be 'sum' or 'mean'")
+    """metric.py:9-38 on dense targets.  reduction 'sum' (default, the only one the reference's own callers use),
+    'mean' (mean of the per-row sums) or anything else (e.g. None): the per-row sums themselves, shape
+    y_pred.shape[:-1], like the reference's fall-through return (:33-38).  from_logits=True applies tf.nn.softmax over
+    the last axis first (:19-20).  Differentiable w.r.t. y_pred when it requires grad; return_grad=True instead
+    returns d loss / d y_pred explicitly (for an un-reduced loss: of each row's sum w.r.t. that row)."""
     lib = _lib.load()
     dev = _lib.require_gpu()
     y_true = _lib.as_dev(y_true, torch.float32, dev).detach()
     y_pred = _lib.as_dev(y_pred, torch.float32, dev)
     if y_true.shape != y_pred.shape:
         raise ValueError('y_true %r and y_pred %r differ in shape' % (tuple(y_true.shape), tuple(y_pred.shape)))
+    if from_logits or reduction not in ('sum', 'mean'):
+        # row by row: the softmax needs the row, the un-reduced return is one value per row
+        if not return_grad and torch.is_grad_enabled() and y_pred.requires_grad:
+            rows, grad = _FocalRowsFn.apply(y_pred, y_true, gamma, alpha, from_logits), None
+        else:
+            rows, grad = _focal_rows_launch(lib, y_true, y_pred.detach(), gamma, alpha, from_logits, return_grad)
+        if reduction == 'sum':
+            loss = rows.sum()
+        elif reduction == 'mean':
+            loss = rows.mean()
+            grad = grad / max(rows.numel(), 1) if grad is not None else None
+        else:
+            loss = rows
+        return (loss, grad) if return_grad else loss
     n = y_pred.numel()
     scale = 1.0
     if reduction == 'mean':

@@ -354,9 +354,18 @@ def focal_loss_elements(y_true, y_pred, gamma=1.5, alpha=0.25):
     return ((-a * w) * np.log(pt)).astype(F32)
 
 
-def focal_loss(y_true, y_pred, gamma=1.5, alpha=0.25, reduction='sum'):
-    """metric.py:9-38 (from_logits=False).  The order of TF's reductions is not specified, so
-    the sums are taken in float64 and compared with a tolerance."""
+def softmax(x):
+    """tf.nn.softmax over the last axis in fp32 (metric.py:19-20): exp(x - max) / sum."""
+    x = _f32(x)
+    e = np.exp(x - x.max(axis=-1, keepdims=True)).astype(F32)
+    return (e / e.sum(axis=-1, keepdims=True, dtype=F32)).astype(F32)
+
+
+def focal_loss(y_true, y_pred, gamma=1.5, alpha=0.25, reduction='sum', from_logits=False):
+    """metric.py:9-38.  The order of TF's reductions is not specified, so the sums are taken in
+    float64 and compared with a tolerance."""
+    if from_logits:
+        y_pred = softmax(y_pred)
     rows = focal_loss_elements(y_true, y_pred, gamma, alpha).sum(axis=-1, dtype=np.float64)
     if reduction == 'mean':
         return rows.mean()

@@ -89,6 +89,47 @@ def test_dense_focal_loss_and_model_metric_signature():
     assert i == 0.
 
 
+@pytest.mark.parametrize('gamma', [1.5, 2.0])
+def test_focal_loss_from_logits_and_unreduced(gamma):
+    """The two forms of metric.py:9-38 that the reference's own callers never use: from_logits=True (tf.nn.softmax over
+    the last axis first, :19-20) and the fall-through return of the per-row sums (:33-38), against the oracle (losses
+    1e-5 relative, the bar of this file) and the gradients against central differences of the float64 oracle."""
+    rng = np.random.default_rng(17)
+    rows, C = (5, 7), 130                                       # a leading shape, a row longer than two wave steps
+    y = np.zeros(rows + (C,), F)
+    hot = rng.integers(0, C, rows)
+    np.put_along_axis(y, hot[..., None], 1.0, axis=-1)
+    z = rng.normal(0, 2.0, rows + (C,)).astype(F)
+    p = rng.uniform(0, 1, rows + (C,)).astype(F)
+    for reduction in ('sum', 'mean', None):
+        got = M.focal_loss(y, z, gamma=gamma, from_logits=True, reduction=reduction)
+        want = O.focal_loss(y, z, gamma, 0.25, reduction, from_logits=True)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=RTOL)
+    got = M.focal_loss(y, p, gamma=gamma, reduction=None)
+    assert tuple(got.shape) == rows
+    np.testing.assert_allclose(got.cpu().numpy(), O.focal_loss(y, p, gamma, 0.25, None), rtol=RTOL)
+    # gradients: explicit and through autograd, through the softmax
+    zt = torch.tensor(z, device='cuda', requires_grad=True)
+    M.focal_loss(y, zt, gamma=gamma, from_logits=True, reduction='sum').backward()
+    loss, g = M.focal_loss(y, z, gamma=gamma, from_logits=True, reduction='sum', return_grad=True)
+    np.testing.assert_array_equal(zt.grad.cpu().numpy(), g.cpu().numpy())
+    g = g.cpu().numpy()
+    h = 1e-3
+    for idx in [(0, 0, int(hot[0, 0])), (2, 3, 5), (4, 6, C - 1), (1, 1, int(hot[1, 1]))]:
+        zp, zm = z.astype(np.float64).copy(), z.astype(np.float64).copy()
+        zp[idx] += h
+        zm[idx] -= h
+
+        def f64(zz):                                           # the oracle's formula in float64 (no fp32 noise in the difference)
+            e = np.exp(zz - zz.max(-1, keepdims=True))
+            q = np.clip(e / e.sum(-1, keepdims=True), 1e-6, 1 - 1e-6)
+            pt = np.where(y == 1, q, 1 - q)
+            a = np.where(y == 1, 0.25, 0.75)
+            return float((-a * (1 - pt) ** gamma * np.log(pt)).sum())
+        num = (f64(zp) - f64(zm)) / (2 * h)
+        np.testing.assert_allclose(g[idx], num, rtol=2e-3, atol=1e-5)
+
+
 def test_cfg2_full_size_loss():
     anchors = O.yolo_shaped_anchors(416)
     gt, lab = workloads.match_inputs(2, batch=16)
