@@ -287,7 +287,7 @@ __global__ __launch_bounds__(WAVE) void score_scan_kernel(hdr_word *hdr, uint32_
             __hip_atomic_store(cand_count + (size_t)i * CNT_STRIDE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane < SCAN_QUEUES)
             __hip_atomic_store(tile_ticket + lane * SCAN_TICKET_STRIDE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane == 0) __hip_atomic_store(coop_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < 2) __hip_atomic_store(coop_count + lane, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one per pass
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every zero has left this wave
         if (lane == 0) __hip_atomic_store(hdr + 1, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -654,10 +654,27 @@ static_assert((size_t)TAIL_SORT_CAP * 8 <= TAIL_LDS_FIT, "finalize block does no
 // pays one compare for it.  A longer list is first sorted by (score desc, anchor asc), in the block's LDS
 // sort buffer up to PART_SORT_CAP keys and in global memory beyond, and cut to the bound; the survivors
 // then go through the partition below like any other list.
+//
+// The score tier (round 3).  Greedy NMS visits a class in score order and a candidate is only ever suppressed by
+// higher-scoring ones, so the kept boxes with score >= t are decided by the candidates with score >= t alone -- and
+// the final list is the max_ret best kept boxes of the image.  Hence: pass 1 runs partition / NMS / final top-k on the
+// image's TIER only, every candidate with score >= t where t is chosen so that the tier holds about TIER_FACTOR *
+// max_ret of them (all ties at t included); if the tier keeps at least max_ret boxes, those ARE the image's
+// detections, bit for bit, and the rest of its candidates (4 500 per image on configs[4], of which the tier is 800)
+// never reach the NMS kernel: its segments shrink from up to 330 candidates to at most a wave's worth, and the
+// latency chain that bounds the launch (the longest class) with them.  An image whose tier keeps fewer than max_ret
+// boxes -- or whose list the pre-NMS top-k cuts, or is longer than the block holds in registers -- is done again by
+// pass 2 on its whole list, exactly as before; the three pass-2 launches are always enqueued (no host round trip)
+// and their blocks leave at once for images that are done (state[b] != 0).
+#ifndef ODBOX_TIER_FACTOR
+#define ODBOX_TIER_FACTOR 8
+#endif
+constexpr uint32_t TIER_BUCKETS = 1024;                   // score histogram of the tier selection (4 KB of LDS)
+
 __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
     const int *__restrict__ cand_count, uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out,
     uint32_t cand_stride, int C, uint32_t pre_nms_topk, int *__restrict__ seg_start, int *__restrict__ coop_count,
-    int *__restrict__ coop_list)
+    int *__restrict__ coop_list, int pass, uint32_t tier_k, int *__restrict__ state, int *__restrict__ fin_count)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_part[];
     const int copies = part_copies(C);
@@ -665,12 +682,24 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
     int *s_scan = s_hist + copies * C;                   // [PART_THREADS] scan scratch, [PART_THREADS] = flag
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     int *my_hist = s_hist + (int)(tid & (uint32_t)(copies - 1)) * C;      // this lane's copy
+    if (pass == 2) {
+        if (state[b] != 0) return;                       // pass 1 finished this image (block-uniform, before any barrier)
+        if (tid == 0) fin_count[b * CNT_STRIDE] = 0;      // what pass 1 kept of it is void
+    }
     Stamps stp;
     uint32_t M = min((uint32_t)cand_count[b * CNT_STRIDE], cand_stride);
     ODBOX_LAP(stp, 0, tid == 0);                          // count loaded
     uint64_t *in = keys_in + (size_t)b * cand_stride;
     uint64_t *out = keys_out + (size_t)b * cand_stride;
-    if (pre_nms_topk != 0u && M > pre_nms_topk) {        // block-uniform
+    constexpr int PART_REG = 16;
+    if (pass == 1 && ((pre_nms_topk != 0u && M > pre_nms_topk) || M > (uint32_t)(PART_REG * PART_THREADS))) {
+        // left to pass 2 whole: an empty tier (no segment, nothing kept, not complete)
+        int *seg = seg_start + (size_t)b * (C + 1);
+        for (int c = tid; c <= C; c += PART_THREADS) seg[c] = 0;
+        if (tid == 0) state[b] = 0;
+        return;
+    }
+    if (pre_nms_topk != 0u && M > pre_nms_topk) {        // block-uniform (pass 2 only)
         // (the LDS sort buffer exists when the list can hold an oversized class segment, see the launch)
         uint64_t *s_sel = reinterpret_cast<uint64_t *>(s_part + part_sort_offset(C));
         if (M <= PART_SORT_CAP && cand_stride > NMS_SEG_LDS) {
@@ -695,7 +724,6 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
     const uint32_t cmax = (uint32_t)C - 1u;
     // the usual list (<= PART_REG * 512 keys) stays in registers between the two passes: every load
     // is issued before the first use, and the scatter pass reads nothing from memory
-    constexpr int PART_REG = 16;
     const bool in_regs = M <= (uint32_t)(PART_REG * PART_THREADS);
     uint64_t kreg[PART_REG];
     if (in_regs) {
@@ -704,9 +732,76 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
             const uint32_t i = tid + (uint32_t)r * PART_THREADS;
             kreg[r] = i < M ? in[i] : ~0ull;
         }
+        if (pass == 1) {
+            // ---- the tier: every candidate whose score bucket is at most the one in which the tier_k-th best falls ----
+            const bool whole = M <= tier_k;              // block-uniform
+            if (!whole) {
+                int *s_tier = reinterpret_cast<int *>(s_part + part_sort_offset(C));      // [TIER_BUCKETS], then {bucket, size}
+                uint32_t lo = 0xffffffffu, hi = 0u;      // the key's score word: smaller = higher score
+#pragma unroll
+                for (int r = 0; r < PART_REG; ++r)
+                    if (kreg[r] != ~0ull) {
+                        const uint32_t sw = (uint32_t)(kreg[r] >> 20);
+                        lo = min(lo, sw);
+                        hi = max(hi, sw);
+                    }
+#pragma unroll
+                for (int off = 1; off < WAVE; off <<= 1) {
+                    lo = min(lo, (uint32_t)__shfl_xor((int)lo, off));
+                    hi = max(hi, (uint32_t)__shfl_xor((int)hi, off));
+                }
+                if ((tid & 63u) == 0u) {
+                    s_scan[tid >> 6] = (int)lo;
+                    s_scan[PART_THREADS / WAVE + (tid >> 6)] = (int)hi;
+                }
+                for (uint32_t i = tid; i < TIER_BUCKETS + 2u; i += PART_THREADS) s_tier[i] = 0;
+                __syncthreads();
+                for (int w = 0; w < PART_THREADS / WAVE; ++w) {
+                    lo = min(lo, (uint32_t)s_scan[w]);
+                    hi = max(hi, (uint32_t)s_scan[PART_THREADS / WAVE + w]);
+                }
+                const uint32_t range = hi - lo;
+                const uint32_t shift = range < TIER_BUCKETS ? 0u : (32u - (uint32_t)__clz((int)range)) - 10u;      // (range >> shift) < 1024
+#pragma unroll
+                for (int r = 0; r < PART_REG; ++r)
+                    if (kreg[r] != ~0ull) atomicAdd(&s_tier[((uint32_t)(kreg[r] >> 20) - lo) >> shift], 1);
+                __syncthreads();
+                // inclusive scan over the buckets, two per thread (PART_THREADS * 2 == TIER_BUCKETS)
+                static_assert(PART_THREADS * 2 == (int)TIER_BUCKETS, "two score buckets per thread");
+                const int h0 = s_tier[2u * tid], h1 = s_tier[2u * tid + 1u];
+                int incl = h0 + h1;
+#pragma unroll
+                for (int off = 1; off < WAVE; off <<= 1) {
+                    const int v = __shfl_up(incl, off);
+                    if ((int)(tid & 63u) >= off) incl += v;
+                }
+                __syncthreads();                         // the lo / hi slots of s_scan have been read by everybody
+                if ((tid & 63u) == 63u) s_scan[tid >> 6] = incl;
+                __syncthreads();
+                int before = incl - (h0 + h1);
+                for (uint32_t w = 0; w < (tid >> 6); ++w) before += s_scan[w];
+                if ((uint32_t)before < tier_k) {         // exactly one thread finds the bucket the tier_k-th best falls into
+                    if ((uint32_t)(before + h0) >= tier_k) {
+                        s_tier[TIER_BUCKETS] = (int)(2u * tid);
+                        s_tier[TIER_BUCKETS + 1u] = before + h0;
+                    } else if ((uint32_t)(before + h0 + h1) >= tier_k) {
+                        s_tier[TIER_BUCKETS] = (int)(2u * tid + 1u);
+                        s_tier[TIER_BUCKETS + 1u] = before + h0 + h1;
+                    }
+                }
+                __syncthreads();
+                const uint32_t last_bucket = (uint32_t)s_tier[TIER_BUCKETS];
+                M = min((uint32_t)s_tier[TIER_BUCKETS + 1u], M);      // the tier's size
+#pragma unroll
+                for (int r = 0; r < PART_REG; ++r)
+                    if (kreg[r] != ~0ull && (((uint32_t)(kreg[r] >> 20) - lo) >> shift) > last_bucket) kreg[r] = ~0ull;
+                __syncthreads();                         // s_scan is used again below
+            }
+            if (tid == 0) state[b] = whole ? 1 : 0;      // 1: the tier is the whole list, whatever it keeps is final
+        }
 #pragma unroll
         for (int r = 0; r < PART_REG; ++r)
-            if (tid + (uint32_t)r * PART_THREADS < M) atomicAdd(&my_hist[min(key_class(kreg[r]), cmax)], 1);
+            if (kreg[r] != ~0ull) atomicAdd(&my_hist[min(key_class(kreg[r]), cmax)], 1);
     } else {
         for (uint32_t i = tid; i < M; i += PART_THREADS) atomicAdd(&my_hist[min(key_class(in[i]), cmax)], 1);
     }
@@ -760,7 +855,7 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
     if (in_regs) {
 #pragma unroll
         for (int r = 0; r < PART_REG; ++r)
-            if (tid + (uint32_t)r * PART_THREADS < M) {
+            if (kreg[r] != ~0ull) {
                 const uint32_t at = (uint32_t)atomicAdd(&my_hist[min(key_class(kreg[r]), cmax)], 1);
                 if (at < M) out[at] = kreg[r];
             }
@@ -897,7 +992,7 @@ __device__ __forceinline__ void nms_wave_segment(
     uint32_t cand_stride, const int *__restrict__ seg_start,
     int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys, uint32_t fin_stride,
     uint32_t total_segments, int waves_per_block, uint32_t per_wave_bytes, uint32_t sort_cap, bool coop_on, bool kept_alias,
-    uint32_t dbg)
+    const int *__restrict__ done, uint32_t dbg)
 {
     ODBOX_NO_EXPERIMENTS(dbg);
     const uint32_t lane = threadIdx.x & 63u;
@@ -907,6 +1002,7 @@ __device__ __forceinline__ void nms_wave_segment(
     Stamps stp;
     const uint32_t b = seg_id / (uint32_t)C;
     const uint32_t c = seg_id - b * (uint32_t)C;
+    if (done && done[b] != 0) return;                    // pass 2: the image's tier was enough
     const int start = seg_start[(size_t)b * (C + 1) + c];
     const int end = seg_start[(size_t)b * (C + 1) + c + 1];
     if (end <= start) return;
@@ -1259,7 +1355,7 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
     const int *__restrict__ coop_count, const int *__restrict__ coop_list, uint32_t coop_blocks,
     int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys, uint32_t fin_stride,
     uint32_t total_segments, int waves_per_block, uint32_t per_wave_bytes, uint32_t sort_cap, uint32_t kept_alias,
-    uint32_t dbg)
+    const int *__restrict__ done, uint32_t dbg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     ODBOX_NO_EXPERIMENTS(dbg);
@@ -1271,7 +1367,7 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
     else
         nms_wave_segment(s_raw, blockIdx.x - coop_blocks, anchors, rb, N, C, do_clip, hi_x, hi_y, thr, max_ret,
                          cand_keys, cand_stride, seg_start, fin_count, fin_keys, fin_stride, total_segments,
-                         waves_per_block, per_wave_bytes, sort_cap, coop_blocks != 0, kept_alias != 0, dbg);
+                         waves_per_block, per_wave_bytes, sort_cap, coop_blocks != 0, kept_alias != 0, done, dbg);
 }
 
 // kernel 4: per image, order the kept detections like tf.math.top_k over the class-ordered
@@ -1290,14 +1386,19 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
     const float4 *__restrict__ anchors, const BoxSrc rb, int N, int do_clip, float hi_x,
     float hi_y, int max_ret, const int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys,
     uint32_t fin_stride, uint32_t lds_keys, float4 *__restrict__ out_boxes, float *__restrict__ out_scores,
-    int32_t *__restrict__ out_labels, int32_t *__restrict__ out_keep, int32_t *__restrict__ out_count, hdr_word *hdr)
+    int32_t *__restrict__ out_labels, int32_t *__restrict__ out_keep, int32_t *__restrict__ out_count, hdr_word *hdr,
+    int pass, int *__restrict__ state)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    if (b == 0 && tid == 0) hdr[0] = hdr[0] + 1ull;           // the call's last kernel: next epoch (see wait_ready)
+    if (hdr && b == 0 && tid == 0) hdr[0] = hdr[0] + 1ull;    // the call's last kernel: next epoch (see wait_ready)
+    if (pass == 2 && state[b] != 0) return;                   // pass 1 wrote this image's detections (block-uniform)
     Stamps stp;
     uint64_t *gk = fin_keys + (size_t)b * fin_stride;
     const uint32_t n = min((uint32_t)fin_count[b * CNT_STRIDE], fin_stride);
+    // pass 1: what the tier kept is the image's answer when the tier was the whole list (state 1, from the partition
+    // kernel) or kept at least max_ret boxes; otherwise pass 2 does the image again and overwrites what is emitted here
+    if (pass == 1 && tid == 0) state[b] = (state[b] != 0 || n >= (uint32_t)max_ret) ? 1 : 0;
     const uint32_t keep = min(n, (uint32_t)max_ret);
     ODBOX_LAP(stp, 56, tid == 0);                             // count loaded
     auto emit = [&](auto k) {
@@ -1690,17 +1791,20 @@ int decode_nms_impl(const char *who, const float *anchors, const void *regress_o
     }
     if (rc) return rc;
 
-    // kernel 2: the pre-NMS top-k where it binds, then group by class (counting sort)
-    // hist + scan scratch, then room to sort one oversized class segment (only lists that can hold one need it)
-    const size_t part_sort = L.cand_stride > NMS_SEG_LDS ? (size_t)(L.cand_stride < PART_SORT_CAP ? L.cand_stride : PART_SORT_CAP) * 8 : 0;
+    // kernels 2-4, twice: pass 1 on every image's score tier, pass 2 on the whole list of the images whose tier did not
+    // keep max_ret boxes (see cand_partition_kernel); pass 2 is left out when no list can be longer than the tier
+    int *state = cand_count + (size_t)2 * B * CNT_STRIDE;          // [B]: 1 = pass 1 finished the image
+    uint32_t tier_k = (uint32_t)ODBOX_TIER_FACTOR * (uint32_t)max_ret;
+    if (const char *e = tuning_env("ODBOX_TIER_FACTOR")) tier_k = atoi(e) > 0 ? (uint32_t)atoi(e) * (uint32_t)max_ret : 0xffffffffu;
+    const int passes = tier_k >= L.cand_stride ? 1 : 2;
+    // hist + scan scratch, then room to sort one oversized class segment (only lists that can hold one need it) or
+    // for the tier selection's score histogram
+    size_t part_sort = L.cand_stride > NMS_SEG_LDS ? (size_t)(L.cand_stride < PART_SORT_CAP ? L.cand_stride : PART_SORT_CAP) * 8 : 0;
+    if (part_sort < (TIER_BUCKETS + 2) * sizeof(int)) part_sort = (TIER_BUCKETS + 2) * sizeof(int);
     const size_t part_lds = part_sort_offset(C) + part_sort;
     if (int r2 = allow_lds(cand_partition_kernel, part_lds)) return r2;
-    hipLaunchKernelGGL(cand_partition_kernel, dim3(B), dim3(PART_THREADS), part_lds, st, cand_count, keys_a, keys_b,
-                       L.cand_stride, C, (uint32_t)pre_nms_topk, seg_start, coop_count, coop_list);
-    if (int r2 = launch_status("cand_partition")) return r2;
     const uint64_t *nms_keys = keys_b;
 
-    // kernel 3: per-(image, class) greedy NMS
     const size_t nms_extra = max_ret > NMS_REG_KEPT ? (size_t)(max_ret - NMS_REG_KEPT) : 0;
     // with the cooperative blocks on, a wave only ever sorts <= NMS_COOP_MIN keys itself
     const size_t kept_bytes = (size_t)((max_ret + 1) & ~1) * 8 + nms_extra * 20;
@@ -1726,24 +1830,37 @@ int decode_nms_impl(const char *who, const float *anchors, const void *regress_o
     if (coop_blocks && nms_lds < COOP_LDS) nms_lds = COOP_LDS;
     const uint64_t nms_grid = (segs + waves - 1) / waves + coop_blocks;
     if (int r3 = allow_lds(nms_kernel, nms_lds)) return r3;
-    hipLaunchKernelGGL(nms_kernel, dim3((uint32_t)nms_grid), dim3(waves * WAVE), nms_lds, st, (const float4 *)anchors,
-                       rb, N, C, do_clip, hi_x, hi_y, nms_thr, max_ret, nms_keys,
-                       L.cand_stride, seg_start, (const int *)coop_count, (const int *)coop_list, coop_blocks,
-                       fin_count, fin_keys, L.fin_stride, (uint32_t)segs, waves, (uint32_t)per_wave, sort_cap, kept_alias,
-                       (uint32_t)(tuning_env("ODBOX_NMS_DBG") ? atoi(tuning_env("ODBOX_NMS_DBG")) : 0));
-    if (int r3 = launch_status("nms")) return r3;
 
-    // kernel 4: final order, top max_ret, zero padding
-    // keys per LDS batch: a multiple of the 128-key chunk, at least two chunks (one carried + one new)
+    // keys per LDS batch of the final kernel: a multiple of the 128-key chunk, at least two chunks (one carried + one new)
     size_t fin_keys_lds = align_up((size_t)(L.fin_stride < TAIL_SORT_CAP ? L.fin_stride : TAIL_SORT_CAP), FIN_CHUNK);
     if (fin_keys_lds < 2 * FIN_CHUNK) fin_keys_lds = 2 * FIN_CHUNK;
     const size_t fin_lds = fin_keys_lds * 8;
     if (int r4 = allow_lds(finalize_kernel, fin_lds)) return r4;
-    hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(FIN_THREADS), fin_lds, st, (const float4 *)anchors,
-                       rb, N, do_clip, hi_x, hi_y, max_ret, fin_count, fin_keys,
-                       L.fin_stride, (uint32_t)fin_keys_lds, (float4 *)out_boxes, out_scores, out_labels, out_keep_anchor,
-                       out_count, hdr);
-    return launch_status("finalize");
+
+    for (int pass = 1; pass <= passes; ++pass) {
+        const bool last = pass == passes;
+        const int kpass = passes == 1 ? 0 : pass;                  // 0: one plain pass (no tier, no per-image state)
+        // kernel 2: (pass 1) the tier, (pass 2) the pre-NMS top-k where it binds; then group by class (counting sort)
+        hipLaunchKernelGGL(cand_partition_kernel, dim3(B), dim3(PART_THREADS), part_lds, st, cand_count, keys_a, keys_b,
+                           L.cand_stride, C, (uint32_t)pre_nms_topk, seg_start, coop_count + (pass - 1), coop_list,
+                           kpass, tier_k, state, fin_count);
+        if (int r2 = launch_status("cand_partition")) return r2;
+        // kernel 3: per-(image, class) greedy NMS
+        hipLaunchKernelGGL(nms_kernel, dim3((uint32_t)nms_grid), dim3(waves * WAVE), nms_lds, st, (const float4 *)anchors,
+                           rb, N, C, do_clip, hi_x, hi_y, nms_thr, max_ret, nms_keys,
+                           L.cand_stride, seg_start, (const int *)(coop_count + (pass - 1)), (const int *)coop_list, coop_blocks,
+                           fin_count, fin_keys, L.fin_stride, (uint32_t)segs, waves, (uint32_t)per_wave, sort_cap, kept_alias,
+                           pass == 2 ? (const int *)state : (const int *)nullptr,
+                           (uint32_t)(tuning_env("ODBOX_NMS_DBG") ? atoi(tuning_env("ODBOX_NMS_DBG")) : 0));
+        if (int r3 = launch_status("nms")) return r3;
+        // kernel 4: final order, top max_ret, zero padding
+        hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(FIN_THREADS), fin_lds, st, (const float4 *)anchors,
+                           rb, N, do_clip, hi_x, hi_y, max_ret, fin_count, fin_keys,
+                           L.fin_stride, (uint32_t)fin_keys_lds, (float4 *)out_boxes, out_scores, out_labels, out_keep_anchor,
+                           out_count, last ? hdr : (hdr_word *)nullptr, kpass, state);
+        if (int r4 = launch_status("finalize")) return r4;
+    }
+    return 0;
 }
 
 }  // namespace

@@ -479,3 +479,48 @@ def test_workspace_with_arbitrary_contents():
             BB.decode_and_nms(other[0], other[1], other[2], (160, 160), return_keep=True)
         got = BB.decode_and_nms(anchors, regress, scores, (160, 160), return_keep=True)
         check(got, want)
+
+
+def test_score_tier_and_its_fallback():
+    """Pass 1 of odbox_decode_nms runs the NMS on every image's score TIER only (the best 8 * max_ret candidates, ties
+    included) and pass 2 redoes the images whose tier kept fewer than max_ret boxes on their whole list.  One batch
+    with all four kinds of image: (0) the tier is enough; (1) the tier is one pile of duplicates that keeps a single
+    box, so the detections come from far below it (fallback); (2) fewer candidates than a tier (whole list in pass
+    1); (3) no candidate at all.  Scores quantised to 1/32: the tier's edge falls inside a run of equal scores."""
+    rng = np.random.default_rng(123)
+    B, N, C, max_ret = 4, 3600, 6, 20                      # tier: 160 candidates
+    side = int(np.ceil(np.sqrt(N / 9)))
+    anchors = O.tile_anchors(O.base_anchors(32, (1, 2, .5)), side, side, 8)[:N]
+    regress = np.clip(rng.normal(0, 0.3, (B, N, 4)), -2, 2).astype(F)
+    scores = rng.uniform(0, 0.25, (B, N, C)).astype(F)
+
+    def hot(b, idx, cls, lo, hi):
+        scores[b, idx, cls] = (np.floor(rng.uniform(lo, hi, len(idx)) * 32) / 32).astype(F)
+
+    idx = rng.choice(N, 900, replace=False)
+    hot(0, idx, rng.integers(0, C, 900), 0.3, 1.0)
+    pile = np.arange(900, 1200)                            # 300 copies of one box, one class, the best scores of the image
+    regress[1, pile] = 0
+    anchors_pile = anchors.copy()
+    anchors_pile[pile] = anchors[17]
+    hot(1, pile, np.full(300, 2), 0.8, 1.0)
+    rest = rng.choice(np.setdiff1d(np.arange(N), pile), 600, replace=False)
+    hot(1, rest, rng.integers(0, C, 600), 0.3, 0.75)
+    few = rng.choice(N, 90, replace=False)
+    hot(2, few, rng.integers(0, C, 90), 0.3, 1.0)
+    S = 8 * side
+    got = BB.decode_and_nms(anchors_pile, regress, scores, (S, S), max_ret=max_ret, return_keep=True)
+    want = c_oracle.decode_nms(anchors_pile, regress, scores, (S, S), max_ret=max_ret, threads=4)
+    check(got, want)
+    cnt = cpu(got[4])
+    assert cnt[0] == max_ret and cnt[1] == max_ret and 0 < cnt[2] <= max_ret and cnt[3] == 0
+    keep1 = cpu(got[3])[1]
+    assert ((keep1 >= 900) & (keep1 < 1200)).sum() == 1   # one box of the pile, the rest from below the tier
+    # the pre-NMS top-k that binds on one image sends that image to pass 2 as well
+    best = scores.max(-1)
+    masked = scores.copy()
+    for b in range(B):
+        order = sorted(range(N), key=lambda i: (-float(best[b, i]), i))
+        masked[b, order[500:]] = 0
+    got = BB.decode_and_nms(anchors_pile, regress, scores, (S, S), max_ret=max_ret, pre_nms_topk=500, return_keep=True)
+    check(got, c_oracle.decode_nms(anchors_pile, regress, masked, (S, S), max_ret=max_ret, threads=4))
