@@ -500,7 +500,7 @@ def main():
             b, s, l = BB.decode_and_nms(anchors5, reg5, sc5, (S5, S5), pre_nms_topk=5000)
             out['det'] = oddist.gather_detections(b, s, l, batch=None)
 
-        wall5, ev5 = timed(nms_step, args.nms_steps, 3, world)
+        wall5, ev5 = timed(nms_step, args.nms_steps, 8, world)
         med5, spr5 = per_step_median(nms_step, per_group=4)
         bytes5 = B5 * workloads.nms_bytes_per_image(N5, C5)
         digest = hashlib.sha1()

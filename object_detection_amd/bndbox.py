@@ -156,6 +156,17 @@ def _decode_nms(anchors, regress_or_boxes, class_scores, im_size, do_clip,
     return boxes, scores, labels
 
 
+def set_nms_tier(factor: int) -> int:
+    """The score tier of `nms` / `decode_and_nms` (`odbox_set_nms_tier`): pass 1 runs the NMS on every image's best
+    factor * max_ret candidates only and pass 2 redoes the images whose tier kept fewer than max_ret boxes; default 8,
+    0 = off.  Same detections either way.  Returns the previous factor."""
+    lib = _lib.load()
+    prev = lib.odbox_set_nms_tier(int(factor))
+    if prev < 0:
+        raise _lib.OdboxError(lib.odbox_last_error().decode())
+    return prev
+
+
 def nms(bboxes, class_scores, score_threshold: float = 0.3, iou_threshold: float = 0.45,
         max_ret: int = 100, pre_nms_topk: int = 0, return_keep: bool = False):
     """bndbox.py:117-252.  bboxes [B,N,4] xyxy, class_scores [B,N,C] ->

@@ -8,6 +8,7 @@
 //
 // Reference citations are file:line under the reference tree (bioothod/object_detection).
 #include "odbox_common.h"
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -669,22 +670,27 @@ static_assert((size_t)TAIL_SORT_CAP * 8 <= TAIL_LDS_FIT, "finalize block does no
 #ifndef ODBOX_TIER_FACTOR
 #define ODBOX_TIER_FACTOR 8
 #endif
+} // namespace
+static std::atomic<int> g_tier_factor{ODBOX_TIER_FACTOR};      // odbox_set_nms_tier
+namespace {
 constexpr uint32_t TIER_BUCKETS = 1024;                   // score histogram of the tier selection (4 KB of LDS)
 
-__global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
+// (a device function of the whole block, PART_THREADS threads: pass 2 of an image runs at the end of the pass-1 final
+// kernel's block of that image, see finalize_kernel)
+__device__ __forceinline__ void partition_image(
+    unsigned char *s_part, uint32_t b, uint32_t total_segments,
     const int *__restrict__ cand_count, uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out,
     uint32_t cand_stride, int C, uint32_t pre_nms_topk, int *__restrict__ seg_start, int *__restrict__ coop_count,
     int *__restrict__ coop_list, int pass, uint32_t tier_k, int *__restrict__ state, int *__restrict__ fin_count)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_part[];
     const int copies = part_copies(C);
     int *s_hist = reinterpret_cast<int *>(s_part);       // [copies][C] counts -> cursors
     int *s_scan = s_hist + copies * C;                   // [PART_THREADS] scan scratch, [PART_THREADS] = flag
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
     int *my_hist = s_hist + (int)(tid & (uint32_t)(copies - 1)) * C;      // this lane's copy
-    if (pass == 2) {
-        if (state[b] != 0) return;                       // pass 1 finished this image (block-uniform, before any barrier)
-        if (tid == 0) fin_count[b * CNT_STRIDE] = 0;      // what pass 1 kept of it is void
+    if (pass == 2 && tid == 0) {
+        fin_count[b * CNT_STRIDE] = 0;                    // what pass 1 kept of the image is void
+        fin_count[b * CNT_STRIDE + 1] = 0;                // segments of the image that pass 2 has finished (nms_kernel)
     }
     Stamps stp;
     uint32_t M = min((uint32_t)cand_count[b * CNT_STRIDE], cand_stride);
@@ -844,7 +850,7 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
         // segments of NMS_COOP_MIN < m <= NMS_SEG_LDS candidates go to the cooperative blocks of the NMS kernel
         if (cnt > NMS_COOP_MIN && cnt <= (int)NMS_SEG_LDS) {
             const uint32_t at = (uint32_t)atomicAdd(coop_count, 1);
-            if (at < gridDim.x * (uint32_t)C) coop_list[at] = (int)(b * (uint32_t)C + (uint32_t)c);
+            if (at < total_segments) coop_list[at] = (int)(b * (uint32_t)C + (uint32_t)c);
         }
         run += cnt;
     }
@@ -886,6 +892,16 @@ __global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
             sort_u64<true>(out + st, m, tid, PART_THREADS);
         }
     }
+}
+
+__global__ __launch_bounds__(PART_THREADS) void cand_partition_kernel(
+    const int *__restrict__ cand_count, uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out,
+    uint32_t cand_stride, int C, uint32_t pre_nms_topk, int *__restrict__ seg_start, int *__restrict__ coop_count,
+    int *__restrict__ coop_list, int pass, uint32_t tier_k, int *__restrict__ state, int *__restrict__ fin_count)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_part[];
+    partition_image(s_part, blockIdx.x, gridDim.x * (uint32_t)C, cand_count, keys_in, keys_out, cand_stride, C, pre_nms_topk,
+                    seg_start, coop_count, coop_list, pass, tier_k, state, fin_count);
 }
 
 // Where a candidate's regression offsets (or its decoded box, anchors == NULL) come from: [B,N,4] fp32, or --
@@ -986,7 +1002,7 @@ constexpr int NMS_WAVES = 8;
 #endif
 constexpr int NMS_REG_KEPT = 128;
 
-__device__ __forceinline__ void nms_wave_segment(
+__device__ __forceinline__ int nms_wave_segment(
     unsigned char *s_raw, uint32_t block, const float4 *__restrict__ anchors, const BoxSrc rb, int N,
     int C, int do_clip, float hi_x, float hi_y, NmsThr thr, int max_ret, const uint64_t *__restrict__ cand_keys,
     uint32_t cand_stride, const int *__restrict__ seg_start,
@@ -998,14 +1014,16 @@ __device__ __forceinline__ void nms_wave_segment(
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t seg_id = block * (uint32_t)waves_per_block + wave;
-    if (seg_id >= total_segments) return;
+    // returns the image whose segment this wave has finished (an empty segment is finished too), or -1 when the
+    // segment is not this wave's to finish: beyond the batch, an image that pass 1 completed, a cooperative block's
+    if (seg_id >= total_segments) return -1;
     Stamps stp;
     const uint32_t b = seg_id / (uint32_t)C;
     const uint32_t c = seg_id - b * (uint32_t)C;
-    if (done && done[b] != 0) return;                    // pass 2: the image's tier was enough
+    if (done && done[b] != 0) return -1;                 // pass 2: the image's tier was enough
     const int start = seg_start[(size_t)b * (C + 1) + c];
     const int end = seg_start[(size_t)b * (C + 1) + c + 1];
-    if (end <= start) return;
+    if (end <= start) return (int)b;
     const uint32_t m = (uint32_t)(end - start);
     const int sl = m <= 16 ? 8 : m <= WAVE ? 16 : 24;     // stamp slots by segment size: tiny / one chunk / two chunks
     ODBOX_LAP(stp, sl + 0, lane == 0);                    // segment bounds loaded
@@ -1025,7 +1043,7 @@ __device__ __forceinline__ void nms_wave_segment(
     const uint64_t *keys = cand_keys + (size_t)b * cand_stride + start;
     // in visiting order already: every segment longer than a wave sorts itself (sorted by the partition kernel)
     const bool presorted = m > NMS_SEG_LDS;
-    if (coop_on && !presorted && m > (uint32_t)NMS_COOP_MIN) return;       // a cooperative block's segment
+    if (coop_on && !presorted && m > (uint32_t)NMS_COOP_MIN) return -1;    // a cooperative block's segment
     uint64_t reg_key = ~0ull;
     const uint64_t *sorted = keys;
     if (!presorted && !(dbg & 1u)) {
@@ -1114,7 +1132,7 @@ __device__ __forceinline__ void nms_wave_segment(
             const uint32_t pos = (uint32_t)(base + __popcll(kmask0) + __popcll(kmask1 & below));
             if (pos < fin_stride) fin_keys[(size_t)b * fin_stride + pos] = cand_to_final(key1);
         }
-        return;
+        return (int)b;
     }
 
     // kept boxes 0..127: lane k & 63 of set A (k < 64) or set B
@@ -1210,6 +1228,7 @@ __device__ __forceinline__ void nms_wave_segment(
         const uint32_t pos = (uint32_t)(out_base + k);
         if (pos < fin_stride) fin_keys[(size_t)b * fin_stride + pos] = cand_to_final(s_key[k]);
     }
+    return (int)b;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1234,12 +1253,13 @@ __device__ __forceinline__ void nms_wave_segment(
 // instead of 18.5 KB with all 512 boxes in LDS: two blocks fit beside the resident score-scan waves of another stream.
 constexpr size_t COOP_LDS = (size_t)NMS_SEG_LDS * (8 + 8) + 2 * WAVE * (16 + 4) + NMS_WAVES * 16 + 16;
 
+template <typename ItemDone>
 __device__ __forceinline__ void nms_coop_block(
     unsigned char *s_raw, uint32_t block, uint32_t nblocks, const float4 *__restrict__ anchors,
     const BoxSrc rb, int N, int C, int do_clip, float hi_x, float hi_y, NmsThr thr, int max_ret,
     const uint64_t *__restrict__ cand_keys, uint32_t cand_stride, const int *__restrict__ seg_start,
     const int *__restrict__ coop_count, const int *__restrict__ coop_list, uint32_t total_segments,
-    int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys, uint32_t fin_stride)
+    int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys, uint32_t fin_stride, bool stay, ItemDone item_done)
 {
     static_assert(NMS_WAVES * WAVE == (int)NMS_SEG_LDS, "one wave per 64-candidate chunk");
     uint64_t *s_key = reinterpret_cast<uint64_t *>(s_raw);                         // sorted keys
@@ -1260,7 +1280,8 @@ __device__ __forceinline__ void nms_coop_block(
         const uint32_t nw = (m + WAVE - 1) / WAVE;
         // waves without a chunk leave at once when this block has no further item: their slots go to
         // the per-wave blocks waiting behind (terminated waves do not count at the barriers)
-        if (items <= (int)nblocks && wave >= nw) return;
+        // (stay: pass 2, where the whole block may have to run an image's final top-k after the item)
+        if (!stay && items <= (int)nblocks && wave >= nw) return;
 
         // (1) rank sort: keys are distinct (the anchor id is part of the key), so the number of smaller
         // keys is the sorted position -- m broadcast LDS reads per thread and one barrier instead of
@@ -1343,31 +1364,8 @@ __device__ __forceinline__ void nms_coop_block(
             if (pos < fin_stride) fin_keys[(size_t)b * fin_stride + pos] = cand_to_final(s_kkey[k]);
         }
         __syncthreads();
+        item_done(b);
     }
-}
-
-// kernel 3: the first coop_blocks blocks take the big segments cooperatively (they start first, so
-// the longest chains overlap everything else), the others run one wave per (image, class) segment.
-__global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
-    const float4 *__restrict__ anchors, const BoxSrc rb, int N, int C, int do_clip,
-    float hi_x, float hi_y, NmsThr thr, int max_ret, const uint64_t *__restrict__ cand_keys,
-    uint32_t cand_stride, const int *__restrict__ seg_start,
-    const int *__restrict__ coop_count, const int *__restrict__ coop_list, uint32_t coop_blocks,
-    int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys, uint32_t fin_stride,
-    uint32_t total_segments, int waves_per_block, uint32_t per_wave_bytes, uint32_t sort_cap, uint32_t kept_alias,
-    const int *__restrict__ done, uint32_t dbg)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    ODBOX_NO_EXPERIMENTS(dbg);
-    if ((dbg & 4u) && blockIdx.x < coop_blocks) return;       // timing experiments: one path only
-    if ((dbg & 8u) && blockIdx.x >= coop_blocks) return;
-    if (blockIdx.x < coop_blocks)
-        nms_coop_block(s_raw, blockIdx.x, coop_blocks, anchors, rb, N, C, do_clip, hi_x, hi_y, thr, max_ret, cand_keys,
-                       cand_stride, seg_start, coop_count, coop_list, total_segments, fin_count, fin_keys, fin_stride);
-    else
-        nms_wave_segment(s_raw, blockIdx.x - coop_blocks, anchors, rb, N, C, do_clip, hi_x, hi_y, thr, max_ret,
-                         cand_keys, cand_stride, seg_start, fin_count, fin_keys, fin_stride, total_segments,
-                         waves_per_block, per_wave_bytes, sort_cap, coop_blocks != 0, kept_alias != 0, done, dbg);
 }
 
 // kernel 4: per image, order the kept detections like tf.math.top_k over the class-ordered
@@ -1377,28 +1375,23 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
 // half (min(A[e], B[127-e]) is bitonic and holds the 128 smallest of both; one register merge
 // sorts it) -- log2(chunks) rounds instead of a full sort of the list.
 #ifndef ODBOX_FIN_THREADS
-#define ODBOX_FIN_THREADS 1024
+#define ODBOX_FIN_THREADS 512                 // = PART_THREADS = the NMS block: the three share blocks in pass 2
 #endif
 constexpr int FIN_THREADS = ODBOX_FIN_THREADS;
 constexpr uint32_t FIN_CHUNK = 128;
 
-__global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
-    const float4 *__restrict__ anchors, const BoxSrc rb, int N, int do_clip, float hi_x,
-    float hi_y, int max_ret, const int *__restrict__ fin_count, uint64_t *__restrict__ fin_keys,
+// (a device function of the whole block, FIN_THREADS threads: pass 2 runs it from the NMS kernel, in the block that
+// finishes an image's last segment)
+__device__ __forceinline__ void finalize_image(
+    uint64_t *s_keys, uint32_t b, const float4 *__restrict__ anchors, const BoxSrc rb, int N, int do_clip, float hi_x,
+    float hi_y, int max_ret, const int *fin_count, uint64_t *fin_keys,
     uint32_t fin_stride, uint32_t lds_keys, float4 *__restrict__ out_boxes, float *__restrict__ out_scores,
-    int32_t *__restrict__ out_labels, int32_t *__restrict__ out_keep, int32_t *__restrict__ out_count, hdr_word *hdr,
-    int pass, int *__restrict__ state)
+    int32_t *__restrict__ out_labels, int32_t *__restrict__ out_keep, int32_t *__restrict__ out_count)
 {
-    extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    if (hdr && b == 0 && tid == 0) hdr[0] = hdr[0] + 1ull;    // the call's last kernel: next epoch (see wait_ready)
-    if (pass == 2 && state[b] != 0) return;                   // pass 1 wrote this image's detections (block-uniform)
+    const uint32_t tid = threadIdx.x;
     Stamps stp;
     uint64_t *gk = fin_keys + (size_t)b * fin_stride;
     const uint32_t n = min((uint32_t)fin_count[b * CNT_STRIDE], fin_stride);
-    // pass 1: what the tier kept is the image's answer when the tier was the whole list (state 1, from the partition
-    // kernel) or kept at least max_ret boxes; otherwise pass 2 does the image again and overwrites what is emitted here
-    if (pass == 1 && tid == 0) state[b] = (state[b] != 0 || n >= (uint32_t)max_ret) ? 1 : 0;
     const uint32_t keep = min(n, (uint32_t)max_ret);
     ODBOX_LAP(stp, 56, tid == 0);                             // count loaded
     auto emit = [&](auto k) {
@@ -1474,6 +1467,125 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
     } else {
         sort_u64<true>(gk, n, tid, FIN_THREADS);
         emit(gk);
+    }
+}
+
+
+// kernel 4.  Pass 1 also decides whether the tier was enough for its image -- it was the whole list (state 1, from the
+// partition kernel) or kept at least max_ret boxes -- and, if not, starts pass 2 of that image right here: the same
+// block partitions the image's whole list (partition_image), so pass 2 costs one more launch (the NMS kernel, whose
+// blocks also run the final top-k of the images they finish), not three.
+__global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
+    const float4 *__restrict__ anchors, const BoxSrc rb, int N, int do_clip, float hi_x,
+    float hi_y, int max_ret, int *fin_count, uint64_t *fin_keys,
+    uint32_t fin_stride, uint32_t lds_keys, float4 *__restrict__ out_boxes, float *__restrict__ out_scores,
+    int32_t *__restrict__ out_labels, int32_t *__restrict__ out_keep, int32_t *__restrict__ out_count, hdr_word *hdr,
+    int pass, int *__restrict__ state,
+    const int *__restrict__ cand_count, uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out,
+    uint32_t cand_stride, int C, uint32_t pre_nms_topk, int *__restrict__ seg_start, int *__restrict__ coop_count,
+    int *__restrict__ coop_list)
+{
+    static_assert(FIN_THREADS == PART_THREADS, "the final kernel's block also partitions");
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_fin[];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    if (hdr && b == 0 && tid == 0) hdr[0] = hdr[0] + 1ull;    // the call's last kernel: next epoch (see wait_ready)
+    bool again = false;                                       // block-uniform
+    if (pass == 1) {
+        const uint32_t n = min((uint32_t)fin_count[b * CNT_STRIDE], fin_stride);
+        again = !(state[b] != 0 || n >= (uint32_t)max_ret);
+    }
+    finalize_image(reinterpret_cast<uint64_t *>(s_fin), b, anchors, rb, N, do_clip, hi_x, hi_y, max_ret, fin_count, fin_keys,
+                   fin_stride, lds_keys, out_boxes, out_scores, out_labels, out_keep, out_count);
+    if (pass != 1) return;
+    __syncthreads();                                          // everybody has read state[b] and is done with the LDS keys
+    if (tid == 0) state[b] = again ? 0 : 1;
+    if (again)
+        partition_image(s_fin, b, gridDim.x * (uint32_t)C, cand_count, keys_in, keys_out, cand_stride, C, pre_nms_topk,
+                        seg_start, coop_count, coop_list, 2, 0u, state, fin_count);
+}
+
+// kernel 3: the first coop_blocks blocks take the big segments cooperatively (they start first, so
+// the longest chains overlap everything else), the others run one wave per (image, class) segment.
+struct FinalArgs {                     // what finalize_image needs beyond the NMS kernel's own arguments
+    uint32_t lds_keys;
+    float4 *out_boxes;
+    float *out_scores;
+    int32_t *out_labels, *out_keep, *out_count;
+};
+
+// fuse (pass 2 only): the block that finishes the LAST of an image's C segments also runs the image's final top-k, so
+// pass 2 is this one launch.  Every block tells how many segments of an image it has finished with one atomic add on
+// the image's counter (fin_count line, word 1; zeroed when pass 2 of the image was started), behind an agent-scope
+// release of the kept keys its waves stored; the block whose add completes the count acquires and reads them.  No
+// block ever waits for another.  Pass 1 and the single plain pass keep their own final kernel and pay none of this.
+template <bool FUSE>
+__global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
+    const float4 *__restrict__ anchors, const BoxSrc rb, int N, int C, int do_clip,
+    float hi_x, float hi_y, NmsThr thr, int max_ret, const uint64_t *__restrict__ cand_keys,
+    uint32_t cand_stride, const int *__restrict__ seg_start,
+    const int *__restrict__ coop_count, const int *__restrict__ coop_list, uint32_t coop_blocks,
+    int *fin_count, uint64_t *fin_keys, uint32_t fin_stride,
+    uint32_t total_segments, int waves_per_block, uint32_t per_wave_bytes, uint32_t sort_cap, uint32_t kept_alias,
+    const int *__restrict__ done, FinalArgs fa, hdr_word *hdr, uint32_t dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    ODBOX_NO_EXPERIMENTS(dbg);
+    if constexpr (!FUSE) {
+        // pass 1 and the single plain pass: exactly the kernel of round 2 (its own final kernel follows)
+        if ((dbg & 4u) && blockIdx.x < coop_blocks) return;       // timing experiments: one path only
+        if ((dbg & 8u) && blockIdx.x >= coop_blocks) return;
+        if (blockIdx.x < coop_blocks)
+            nms_coop_block(s_raw, blockIdx.x, coop_blocks, anchors, rb, N, C, do_clip, hi_x, hi_y, thr, max_ret, cand_keys,
+                           cand_stride, seg_start, coop_count, coop_list, total_segments, fin_count, fin_keys, fin_stride, false,
+                           [](uint32_t) {});
+        else
+            nms_wave_segment(s_raw, blockIdx.x - coop_blocks, anchors, rb, N, C, do_clip, hi_x, hi_y, thr, max_ret,
+                             cand_keys, cand_stride, seg_start, fin_count, fin_keys, fin_stride, total_segments,
+                             waves_per_block, per_wave_bytes, sort_cap, coop_blocks != 0, kept_alias != 0, done, dbg);
+    } else {
+        __shared__ int s_owner[NMS_WAVES];
+        __shared__ int s_last;
+        if (hdr && blockIdx.x == 0 && threadIdx.x == 0) hdr[0] = hdr[0] + 1ull;      // the call's last kernel: next epoch (see wait_ready)
+        // called by every thread of the block with block-uniform arguments
+        auto segments_done = [&](uint32_t b, int count) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's kept keys have left it
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int before = atomicAdd(fin_count + b * CNT_STRIDE + 1, count);
+                const bool last = before + count >= C;
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                s_last = last ? 1 : 0;
+            }
+            __syncthreads();
+            if (s_last != 0)
+                finalize_image(reinterpret_cast<uint64_t *>(s_raw), b, anchors, rb, N, do_clip, hi_x, hi_y, max_ret, fin_count,
+                               fin_keys, fin_stride, fa.lds_keys, fa.out_boxes, fa.out_scores, fa.out_labels, fa.out_keep, fa.out_count);
+            __syncthreads();                                       // s_last and the LDS are free again
+        };
+        if (blockIdx.x < coop_blocks) {
+            nms_coop_block(s_raw, blockIdx.x, coop_blocks, anchors, rb, N, C, do_clip, hi_x, hi_y, thr, max_ret, cand_keys,
+                           cand_stride, seg_start, coop_count, coop_list, total_segments, fin_count, fin_keys, fin_stride, true,
+                           [&](uint32_t b) { segments_done(b, 1); });
+            return;
+        }
+        const int owner = nms_wave_segment(s_raw, blockIdx.x - coop_blocks, anchors, rb, N, C, do_clip, hi_x, hi_y, thr, max_ret,
+                                           cand_keys, cand_stride, seg_start, fin_count, fin_keys, fin_stride, total_segments,
+                                           waves_per_block, per_wave_bytes, sort_cap, coop_blocks != 0, kept_alias != 0, done, dbg);
+        if ((threadIdx.x & 63u) == 0u) s_owner[threadIdx.x >> 6] = owner;
+        __syncthreads();
+        // the block's segments are consecutive, so the waves that finished segments of one image are neighbours
+        for (int w = 0; w < waves_per_block;) {
+            const int ob = s_owner[w];
+            int w2 = w;
+            while (w2 < waves_per_block && s_owner[w2] == ob) ++w2;
+            if (ob >= 0) segments_done((uint32_t)ob, w2 - w);
+            w = w2;
+        }
     }
 }
 
@@ -1709,6 +1821,12 @@ extern "C" int odbox_debug_stamps(unsigned long long *sum, unsigned long long *m
 
 extern "C" {
 
+int odbox_set_nms_tier(int factor)
+{
+    if (factor < 0 || factor > 4096) return fail(ODBOX_EINVAL, "odbox_set_nms_tier: factor %d (0 = off, at most 4096)", factor);
+    return g_tier_factor.exchange(factor, std::memory_order_relaxed);
+}
+
 size_t odbox_decode_nms_workspace(int B, int N, int C, int max_ret, int pre_nms_topk)
 {
     (void)pre_nms_topk;
@@ -1794,9 +1912,10 @@ int decode_nms_impl(const char *who, const float *anchors, const void *regress_o
     // kernels 2-4, twice: pass 1 on every image's score tier, pass 2 on the whole list of the images whose tier did not
     // keep max_ret boxes (see cand_partition_kernel); pass 2 is left out when no list can be longer than the tier
     int *state = cand_count + (size_t)2 * B * CNT_STRIDE;          // [B]: 1 = pass 1 finished the image
-    uint32_t tier_k = (uint32_t)ODBOX_TIER_FACTOR * (uint32_t)max_ret;
-    if (const char *e = tuning_env("ODBOX_TIER_FACTOR")) tier_k = atoi(e) > 0 ? (uint32_t)atoi(e) * (uint32_t)max_ret : 0xffffffffu;
-    const int passes = tier_k >= L.cand_stride ? 1 : 2;
+    const int tier_factor = g_tier_factor.load(std::memory_order_relaxed);      // odbox_set_nms_tier; 0 = no tier
+    const uint64_t tier_want = (uint64_t)tier_factor * (uint64_t)max_ret;
+    const uint32_t tier_k = tier_factor > 0 && tier_want < 0xffffffffull ? (uint32_t)tier_want : 0xffffffffu;
+    int passes = tier_k >= L.cand_stride ? 1 : 2;
     // hist + scan scratch, then room to sort one oversized class segment (only lists that can hold one need it) or
     // for the tier selection's score histogram
     size_t part_sort = L.cand_stride > NMS_SEG_LDS ? (size_t)(L.cand_stride < PART_SORT_CAP ? L.cand_stride : PART_SORT_CAP) * 8 : 0;
@@ -1829,36 +1948,48 @@ int decode_nms_impl(const char *who, const float *anchors, const void *regress_o
     size_t nms_lds = per_wave * waves;
     if (coop_blocks && nms_lds < COOP_LDS) nms_lds = COOP_LDS;
     const uint64_t nms_grid = (segs + waves - 1) / waves + coop_blocks;
-    if (int r3 = allow_lds(nms_kernel, nms_lds)) return r3;
+    if (int r3 = allow_lds(nms_kernel<false>, nms_lds)) return r3;
 
     // keys per LDS batch of the final kernel: a multiple of the 128-key chunk, at least two chunks (one carried + one new)
     size_t fin_keys_lds = align_up((size_t)(L.fin_stride < TAIL_SORT_CAP ? L.fin_stride : TAIL_SORT_CAP), FIN_CHUNK);
     if (fin_keys_lds < 2 * FIN_CHUNK) fin_keys_lds = 2 * FIN_CHUNK;
     const size_t fin_lds = fin_keys_lds * 8;
-    if (int r4 = allow_lds(finalize_kernel, fin_lds)) return r4;
+    if (waves != NMS_WAVES) passes = 1;                            // pass 2 runs the final top-k inside full NMS blocks
+    const size_t fin_part_lds = passes == 2 && part_lds > fin_lds ? part_lds : fin_lds;      // pass 1: final top-k, then partition_image
+    const size_t nms2_lds = nms_lds > fin_lds ? nms_lds : fin_lds;
+    if (int r4 = allow_lds(finalize_kernel, fin_part_lds)) return r4;
+    if (int r5 = allow_lds(nms_kernel<true>, nms2_lds)) return r5;
 
-    for (int pass = 1; pass <= passes; ++pass) {
-        const bool last = pass == passes;
-        const int kpass = passes == 1 ? 0 : pass;                  // 0: one plain pass (no tier, no per-image state)
-        // kernel 2: (pass 1) the tier, (pass 2) the pre-NMS top-k where it binds; then group by class (counting sort)
-        hipLaunchKernelGGL(cand_partition_kernel, dim3(B), dim3(PART_THREADS), part_lds, st, cand_count, keys_a, keys_b,
-                           L.cand_stride, C, (uint32_t)pre_nms_topk, seg_start, coop_count + (pass - 1), coop_list,
-                           kpass, tier_k, state, fin_count);
-        if (int r2 = launch_status("cand_partition")) return r2;
-        // kernel 3: per-(image, class) greedy NMS
-        hipLaunchKernelGGL(nms_kernel, dim3((uint32_t)nms_grid), dim3(waves * WAVE), nms_lds, st, (const float4 *)anchors,
+    const FinalArgs fa = {(uint32_t)fin_keys_lds, (float4 *)out_boxes, out_scores, out_labels, out_keep_anchor, out_count};
+    const uint32_t nms_dbg = (uint32_t)(tuning_env("ODBOX_NMS_DBG") ? atoi(tuning_env("ODBOX_NMS_DBG")) : 0);
+    const int kpass = passes == 1 ? 0 : 1;                         // 0: one plain pass (no tier, no per-image state)
+    // kernel 2: (pass 1) the tier; (plain pass) the pre-NMS top-k where it binds; then group by class (counting sort)
+    hipLaunchKernelGGL(cand_partition_kernel, dim3(B), dim3(PART_THREADS), part_lds, st, cand_count, keys_a, keys_b,
+                       L.cand_stride, C, (uint32_t)pre_nms_topk, seg_start, coop_count, coop_list, kpass, tier_k, state, fin_count);
+    if (int r2 = launch_status("cand_partition")) return r2;
+    // kernel 3: per-(image, class) greedy NMS
+    hipLaunchKernelGGL(nms_kernel<false>, dim3((uint32_t)nms_grid), dim3(waves * WAVE), nms_lds, st, (const float4 *)anchors,
+                       rb, N, C, do_clip, hi_x, hi_y, nms_thr, max_ret, nms_keys,
+                       L.cand_stride, seg_start, (const int *)coop_count, (const int *)coop_list, coop_blocks,
+                       fin_count, fin_keys, L.fin_stride, (uint32_t)segs, waves, (uint32_t)per_wave, sort_cap, kept_alias,
+                       (const int *)nullptr, fa, (hdr_word *)nullptr, nms_dbg);
+    if (int r3 = launch_status("nms")) return r3;
+    // kernel 4: final order, top max_ret, zero padding; in pass 1 also the partition of pass 2 for the images that need it
+    hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(FIN_THREADS), fin_part_lds, st, (const float4 *)anchors,
+                       rb, N, do_clip, hi_x, hi_y, max_ret, fin_count, fin_keys,
+                       L.fin_stride, (uint32_t)fin_keys_lds, (float4 *)out_boxes, out_scores, out_labels, out_keep_anchor,
+                       out_count, passes == 1 ? hdr : (hdr_word *)nullptr, kpass, state,
+                       (const int *)cand_count, keys_a, keys_b, L.cand_stride, C, (uint32_t)pre_nms_topk, seg_start, coop_count + 1,
+                       coop_list);
+    if (int r4 = launch_status("finalize")) return r4;
+    if (passes == 2) {
+        // pass 2: the NMS of the images whose tier was not enough, with their final top-k in the same launch
+        hipLaunchKernelGGL(nms_kernel<true>, dim3((uint32_t)nms_grid), dim3(waves * WAVE), nms2_lds, st, (const float4 *)anchors,
                            rb, N, C, do_clip, hi_x, hi_y, nms_thr, max_ret, nms_keys,
-                           L.cand_stride, seg_start, (const int *)(coop_count + (pass - 1)), (const int *)coop_list, coop_blocks,
+                           L.cand_stride, seg_start, (const int *)(coop_count + 1), (const int *)coop_list, coop_blocks,
                            fin_count, fin_keys, L.fin_stride, (uint32_t)segs, waves, (uint32_t)per_wave, sort_cap, kept_alias,
-                           pass == 2 ? (const int *)state : (const int *)nullptr,
-                           (uint32_t)(tuning_env("ODBOX_NMS_DBG") ? atoi(tuning_env("ODBOX_NMS_DBG")) : 0));
-        if (int r3 = launch_status("nms")) return r3;
-        // kernel 4: final order, top max_ret, zero padding
-        hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(FIN_THREADS), fin_lds, st, (const float4 *)anchors,
-                           rb, N, do_clip, hi_x, hi_y, max_ret, fin_count, fin_keys,
-                           L.fin_stride, (uint32_t)fin_keys_lds, (float4 *)out_boxes, out_scores, out_labels, out_keep_anchor,
-                           out_count, last ? hdr : (hdr_word *)nullptr, kpass, state);
-        if (int r4 = launch_status("finalize")) return r4;
+                           (const int *)state, fa, hdr, nms_dbg);
+        if (int r5 = launch_status("nms (pass 2)")) return r5;
     }
     return 0;
 }

@@ -512,6 +512,12 @@ def test_score_tier_and_its_fallback():
     got = BB.decode_and_nms(anchors_pile, regress, scores, (S, S), max_ret=max_ret, return_keep=True)
     want = c_oracle.decode_nms(anchors_pile, regress, scores, (S, S), max_ret=max_ret, threads=4)
     check(got, want)
+    for factor in (0, 1, 3):                                 # no tier; every long list falls through to pass 2; a narrow tier
+        prev = BB.set_nms_tier(factor)
+        try:
+            check(BB.decode_and_nms(anchors_pile, regress, scores, (S, S), max_ret=max_ret, return_keep=True), want)
+        finally:
+            assert BB.set_nms_tier(prev) == factor
     cnt = cpu(got[4])
     assert cnt[0] == max_ret and cnt[1] == max_ret and 0 < cnt[2] <= max_ret and cnt[3] == 0
     keep1 = cpu(got[3])[1]
