@@ -1,6 +1,6 @@
 """One mode of bench.py's headline workload (configs[1] match+encode), for the PMC passes of tools/profile_round.sh:
     python3 tools/pmc_headline.py stream|auto|resident [steps]
-stream / auto: five output sets in rotation under that output policy; resident: one set rewritten in place."""
+stream / auto: five output sets in rotation under that output policy; resident: one set rewritten in place under 'cache'."""
 import os
 import sys
 
@@ -18,7 +18,7 @@ dev = _lib.require_gpu()
 anchors = bench.yolo_grid_anchors(416)
 step, w = bench.match_encode_case(lib, dev, _lib.stream_ptr(), 2, workloads.CONFIGS[2]['B'], anchors, 1002,
                                   1 if mode == 'resident' else bench.OUTPUT_SETS)
-lib.odbox_set_output_policy(2 if mode == 'stream' else 0)
+lib.odbox_set_output_policy({'stream': 2, 'auto': 0, 'resident': 1}[mode])      # resident: through the caches ('cache')
 for i in range(steps):
     step(i)
 torch.cuda.synchronize()
