@@ -252,6 +252,13 @@ int odbox_scale_boxes(const float *boxes /*[n,4]*/, size_t n, float fx, float fy
  * than one candidate in eight).  Process-wide; returns the previous factor, or ODBOX_EINVAL. */
 int odbox_set_nms_tier(int factor);
 
+/* Pass 1 of odbox_decode_nms as ONE launch (no counterpart in the reference; the same bits either way).  on = 1
+ * (default): tier selection, class partition, per-class NMS and the final top-k of an image run in one block, one
+ * candidate per lane, whenever the tier fits it (max_ret <= 113 at the default tier factor; C <= 2048); a call is then
+ * three launches: score scan, this kernel, pass 2.  on = 0: the separate partition / NMS / final kernels, as for
+ * shapes the fused block does not hold.  Process-wide; returns the previous setting, or ODBOX_EINVAL. */
+int odbox_set_nms_fused_tail(int on);
+
 /* Bytes of device workspace odbox_decode_nms needs for these sizes (0 on bad arguments). */
 size_t odbox_decode_nms_workspace(int B, int N, int C, int max_ret, int pre_nms_topk);
 

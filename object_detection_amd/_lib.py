@@ -45,6 +45,7 @@ SIGNATURES = {
     'odbox_focal_loss_workspace': (_sz, [_sz]),
     'odbox_focal_loss': (_i, [_vp, _vp, _sz, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     'odbox_set_nms_tier': (_i, [_i]),
+    'odbox_set_nms_fused_tail': (_i, [_i]),
     'odbox_focal_loss_rows': (_i, [_vp, _vp, _sz, _i, _f, _f, _i, _vp, _vp, _vp]),
     'odbox_bbox_overlap': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'odbox_bbox_transform': (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),

@@ -167,6 +167,16 @@ def set_nms_tier(factor: int) -> int:
     return prev
 
 
+def set_nms_fused_tail(on: bool) -> bool:
+    """Pass 1 of `nms` / `decode_and_nms` as one launch (`odbox_set_nms_fused_tail`; default on) or as the separate
+    partition / NMS / final kernels.  Same detections either way.  Returns the previous setting."""
+    lib = _lib.load()
+    prev = lib.odbox_set_nms_fused_tail(1 if on else 0)
+    if prev < 0:
+        raise _lib.OdboxError(lib.odbox_last_error().decode())
+    return bool(prev)
+
+
 def nms(bboxes, class_scores, score_threshold: float = 0.3, iou_threshold: float = 0.45,
         max_ret: int = 100, pre_nms_topk: int = 0, return_keep: bool = False):
     """bndbox.py:117-252.  bboxes [B,N,4] xyxy, class_scores [B,N,C] ->

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(WAVE) void score_scan_kernel(hdr_word *hdr, uint32_
             __hip_atomic_store(cand_count + (size_t)i * CNT_STRIDE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane < SCAN_QUEUES)
             __hip_atomic_store(tile_ticket + lane * SCAN_TICKET_STRIDE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane < 2) __hip_atomic_store(coop_count + lane, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one per pass
+        if (lane < 3) __hip_atomic_store(coop_count + lane, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one per pass, then the number of images left to pass 2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every zero has left this wave
         if (lane == 0) __hip_atomic_store(hdr + 1, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -672,8 +672,83 @@ static_assert((size_t)TAIL_SORT_CAP * 8 <= TAIL_LDS_FIT, "finalize block does no
 #endif
 } // namespace
 static std::atomic<int> g_tier_factor{ODBOX_TIER_FACTOR};      // odbox_set_nms_tier
+static std::atomic<int> g_fused_tail{1};                       // odbox_set_nms_fused_tail
 namespace {
 constexpr uint32_t TIER_BUCKETS = 1024;                   // score histogram of the tier selection (4 KB of LDS)
+
+constexpr int PART_REG = 16;                              // keys per thread that a partition block holds in registers
+
+// The tier of one image, by the whole block (THREADS threads; kreg = the image's keys, ~0 = none): marks every key
+// outside the tier ~0 and returns the tier's size.  The cut is found without a sort: a TIER_BUCKETS-bucket histogram
+// over the top bits of the (order-preserving) score word, the bucket in which the running count passes tier_k taken
+// whole (ties included, so the tier is a score threshold, not a count).  s_tier: TIER_BUCKETS + 2 ints of LDS, s_scan:
+// 2 * THREADS / WAVE ints; the caller puts a barrier behind the call before it reuses either.
+template <int THREADS, int REG>
+__device__ __forceinline__ uint32_t tier_select(uint64_t (&kreg)[REG], uint32_t M, uint32_t tier_k, int *s_tier, int *s_scan,
+                                                uint32_t tid)
+{
+    constexpr int NW = THREADS / WAVE;                   // waves of the block
+    constexpr uint32_t BPT = TIER_BUCKETS / THREADS;     // score buckets per thread in the scan
+    static_assert(BPT * THREADS == TIER_BUCKETS && (BPT == 1 || BPT == 2), "one or two score buckets per thread");
+    uint32_t lo = 0xffffffffu, hi = 0u;      // the key's score word: smaller = higher score
+#pragma unroll
+    for (int r = 0; r < REG; ++r)
+        if (kreg[r] != ~0ull) {
+            const uint32_t sw = (uint32_t)(kreg[r] >> 20);
+            lo = min(lo, sw);
+            hi = max(hi, sw);
+        }
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, off));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, off));
+    }
+    if ((tid & 63u) == 0u) {
+        s_scan[tid >> 6] = (int)lo;
+        s_scan[NW + (tid >> 6)] = (int)hi;
+    }
+    for (uint32_t i = tid; i < TIER_BUCKETS + 2u; i += THREADS) s_tier[i] = 0;
+    __syncthreads();
+    for (int w = 0; w < NW; ++w) {
+        lo = min(lo, (uint32_t)s_scan[w]);
+        hi = max(hi, (uint32_t)s_scan[NW + w]);
+    }
+    const uint32_t range = hi - lo;
+    const uint32_t shift = range < TIER_BUCKETS ? 0u : (32u - (uint32_t)__clz((int)range)) - 10u;      // (range >> shift) < 1024
+#pragma unroll
+    for (int r = 0; r < REG; ++r)
+        if (kreg[r] != ~0ull) atomicAdd(&s_tier[((uint32_t)(kreg[r] >> 20) - lo) >> shift], 1);
+    __syncthreads();
+    // inclusive scan over the buckets, BPT per thread
+    const int h0 = s_tier[BPT * tid], h1 = BPT == 2 ? s_tier[BPT * tid + 1u] : 0;
+    int incl = h0 + h1;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if ((int)(tid & 63u) >= off) incl += v;
+    }
+    __syncthreads();                         // the lo / hi slots of s_scan have been read by everybody
+    if ((tid & 63u) == 63u) s_scan[tid >> 6] = incl;
+    __syncthreads();
+    int before = incl - (h0 + h1);
+    for (uint32_t w = 0; w < (tid >> 6); ++w) before += s_scan[w];
+    if ((uint32_t)before < tier_k) {         // exactly one thread finds the bucket the tier_k-th best falls into
+        if ((uint32_t)(before + h0) >= tier_k) {
+            s_tier[TIER_BUCKETS] = (int)(BPT * tid);
+            s_tier[TIER_BUCKETS + 1u] = before + h0;
+        } else if (BPT == 2 && (uint32_t)(before + h0 + h1) >= tier_k) {
+            s_tier[TIER_BUCKETS] = (int)(BPT * tid + 1u);
+            s_tier[TIER_BUCKETS + 1u] = before + h0 + h1;
+        }
+    }
+    __syncthreads();
+    const uint32_t last_bucket = (uint32_t)s_tier[TIER_BUCKETS];
+    M = min((uint32_t)s_tier[TIER_BUCKETS + 1u], M);      // the tier's size
+#pragma unroll
+    for (int r = 0; r < REG; ++r)
+        if (kreg[r] != ~0ull && (((uint32_t)(kreg[r] >> 20) - lo) >> shift) > last_bucket) kreg[r] = ~0ull;
+    return M;
+}
 
 // (a device function of the whole block, PART_THREADS threads: pass 2 of an image runs at the end of the pass-1 final
 // kernel's block of that image, see finalize_kernel)
@@ -697,7 +772,6 @@ __device__ __forceinline__ void partition_image(
     ODBOX_LAP(stp, 0, tid == 0);                          // count loaded
     uint64_t *in = keys_in + (size_t)b * cand_stride;
     uint64_t *out = keys_out + (size_t)b * cand_stride;
-    constexpr int PART_REG = 16;
     if (pass == 1 && ((pre_nms_topk != 0u && M > pre_nms_topk) || M > (uint32_t)(PART_REG * PART_THREADS))) {
         // left to pass 2 whole: an empty tier (no segment, nothing kept, not complete)
         int *seg = seg_start + (size_t)b * (C + 1);
@@ -742,65 +816,7 @@ __device__ __forceinline__ void partition_image(
             // ---- the tier: every candidate whose score bucket is at most the one in which the tier_k-th best falls ----
             const bool whole = M <= tier_k;              // block-uniform
             if (!whole) {
-                int *s_tier = reinterpret_cast<int *>(s_part + part_sort_offset(C));      // [TIER_BUCKETS], then {bucket, size}
-                uint32_t lo = 0xffffffffu, hi = 0u;      // the key's score word: smaller = higher score
-#pragma unroll
-                for (int r = 0; r < PART_REG; ++r)
-                    if (kreg[r] != ~0ull) {
-                        const uint32_t sw = (uint32_t)(kreg[r] >> 20);
-                        lo = min(lo, sw);
-                        hi = max(hi, sw);
-                    }
-#pragma unroll
-                for (int off = 1; off < WAVE; off <<= 1) {
-                    lo = min(lo, (uint32_t)__shfl_xor((int)lo, off));
-                    hi = max(hi, (uint32_t)__shfl_xor((int)hi, off));
-                }
-                if ((tid & 63u) == 0u) {
-                    s_scan[tid >> 6] = (int)lo;
-                    s_scan[PART_THREADS / WAVE + (tid >> 6)] = (int)hi;
-                }
-                for (uint32_t i = tid; i < TIER_BUCKETS + 2u; i += PART_THREADS) s_tier[i] = 0;
-                __syncthreads();
-                for (int w = 0; w < PART_THREADS / WAVE; ++w) {
-                    lo = min(lo, (uint32_t)s_scan[w]);
-                    hi = max(hi, (uint32_t)s_scan[PART_THREADS / WAVE + w]);
-                }
-                const uint32_t range = hi - lo;
-                const uint32_t shift = range < TIER_BUCKETS ? 0u : (32u - (uint32_t)__clz((int)range)) - 10u;      // (range >> shift) < 1024
-#pragma unroll
-                for (int r = 0; r < PART_REG; ++r)
-                    if (kreg[r] != ~0ull) atomicAdd(&s_tier[((uint32_t)(kreg[r] >> 20) - lo) >> shift], 1);
-                __syncthreads();
-                // inclusive scan over the buckets, two per thread (PART_THREADS * 2 == TIER_BUCKETS)
-                static_assert(PART_THREADS * 2 == (int)TIER_BUCKETS, "two score buckets per thread");
-                const int h0 = s_tier[2u * tid], h1 = s_tier[2u * tid + 1u];
-                int incl = h0 + h1;
-#pragma unroll
-                for (int off = 1; off < WAVE; off <<= 1) {
-                    const int v = __shfl_up(incl, off);
-                    if ((int)(tid & 63u) >= off) incl += v;
-                }
-                __syncthreads();                         // the lo / hi slots of s_scan have been read by everybody
-                if ((tid & 63u) == 63u) s_scan[tid >> 6] = incl;
-                __syncthreads();
-                int before = incl - (h0 + h1);
-                for (uint32_t w = 0; w < (tid >> 6); ++w) before += s_scan[w];
-                if ((uint32_t)before < tier_k) {         // exactly one thread finds the bucket the tier_k-th best falls into
-                    if ((uint32_t)(before + h0) >= tier_k) {
-                        s_tier[TIER_BUCKETS] = (int)(2u * tid);
-                        s_tier[TIER_BUCKETS + 1u] = before + h0;
-                    } else if ((uint32_t)(before + h0 + h1) >= tier_k) {
-                        s_tier[TIER_BUCKETS] = (int)(2u * tid + 1u);
-                        s_tier[TIER_BUCKETS + 1u] = before + h0 + h1;
-                    }
-                }
-                __syncthreads();
-                const uint32_t last_bucket = (uint32_t)s_tier[TIER_BUCKETS];
-                M = min((uint32_t)s_tier[TIER_BUCKETS + 1u], M);      // the tier's size
-#pragma unroll
-                for (int r = 0; r < PART_REG; ++r)
-                    if (kreg[r] != ~0ull && (((uint32_t)(kreg[r] >> 20) - lo) >> shift) > last_bucket) kreg[r] = ~0ull;
+                M = tier_select<PART_THREADS, PART_REG>(kreg, M, tier_k, reinterpret_cast<int *>(s_part + part_sort_offset(C)), s_scan, tid);
                 __syncthreads();                         // s_scan is used again below
             }
             if (tid == 0) state[b] = whole ? 1 : 0;      // 1: the tier is the whole list, whatever it keeps is final
@@ -1380,6 +1396,69 @@ __device__ __forceinline__ void nms_coop_block(
 constexpr int FIN_THREADS = ODBOX_FIN_THREADS;
 constexpr uint32_t FIN_CHUNK = 128;
 
+// The FIN_CHUNK smallest of nchunks * FIN_CHUNK keys in LDS (~0 = none), sorted, into chunk 0; by the whole block
+// (NWAVES waves), which has a barrier behind it before and after.  Every wave sorts 128-key chunks in registers,
+// then chunk pairs are merged keeping the lower half: min(A[e], B[127-e]) is bitonic and holds the 128 smallest of
+// both, one register merge sorts it -- log2(chunks) rounds instead of a full sort.
+template <int NWAVES = FIN_THREADS / WAVE>
+__device__ __forceinline__ void best128_of_chunks(uint64_t *s_keys, uint32_t nchunks, uint32_t tid)
+{
+    const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = NWAVES;
+    for (uint32_t c = wave; c < nchunks; c += nwaves) {
+        uint64_t k[2];
+        uint64_t *ch = s_keys + c * FIN_CHUNK;
+        k[0] = ch[lane * 2];
+        k[1] = ch[lane * 2 + 1];
+        wave_sort_regs<2>(k, lane);
+        ch[lane * 2] = k[0];
+        ch[lane * 2 + 1] = k[1];
+    }
+    __syncthreads();
+    for (uint32_t stride = 1; stride < nchunks; stride <<= 1) {
+        for (uint32_t c = wave * 2 * stride; c + stride < nchunks; c += nwaves * 2 * stride) {
+            uint64_t *lo = s_keys + c * FIN_CHUNK;
+            const uint64_t *hi = s_keys + (c + stride) * FIN_CHUNK;
+            uint64_t k[2];
+#pragma unroll
+            for (uint32_t s0 = 0; s0 < 2; ++s0) {
+                const uint32_t e = lane * 2 + s0;
+                const uint64_t x = lo[e], y = hi[FIN_CHUNK - 1 - e];
+                k[s0] = x < y ? x : y;
+            }
+            wave_sort_regs<2, true>(k, lane);
+            lo[lane * 2] = k[0];
+            lo[lane * 2 + 1] = k[1];
+        }
+        __syncthreads();
+    }
+}
+
+// the image's detections out of its sorted final keys k[0 .. keep): decode the winners, zero-pad to max_ret
+// (bndbox.py:233-244)
+template <typename Keys>
+__device__ __forceinline__ void emit_detections(
+    Keys k, uint32_t keep, uint32_t b, const float4 *__restrict__ anchors, const BoxSrc rb, int N, int do_clip, float hi_x,
+    float hi_y, int max_ret, float4 *__restrict__ out_boxes, float *__restrict__ out_scores, int32_t *__restrict__ out_labels,
+    int32_t *__restrict__ out_keep)
+{
+    for (uint32_t r = threadIdx.x; r < (uint32_t)max_ret; r += FIN_THREADS) {
+        const size_t o = (size_t)b * max_ret + r;
+        if (r < keep) {
+            const uint64_t ck = final_to_cand(k[r]);
+            const uint32_t idx = key_anchor(ck);
+            out_boxes[o] = candidate_box(anchors, rb, b, N, idx, do_clip, hi_x, hi_y);
+            out_scores[o] = key_score(ck);
+            out_labels[o] = (int32_t)key_class(ck);
+            if (out_keep) out_keep[o] = (int32_t)idx;
+        } else {
+            out_boxes[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+            out_scores[o] = 0.0f;
+            out_labels[o] = 0;
+            if (out_keep) out_keep[o] = -1;
+        }
+    }
+}
+
 // (a device function of the whole block, FIN_THREADS threads: pass 2 runs it from the NMS kernel, in the block that
 // finishes an image's last segment)
 __device__ __forceinline__ void finalize_image(
@@ -1395,28 +1474,12 @@ __device__ __forceinline__ void finalize_image(
     const uint32_t keep = min(n, (uint32_t)max_ret);
     ODBOX_LAP(stp, 56, tid == 0);                             // count loaded
     auto emit = [&](auto k) {
-        for (uint32_t r = tid; r < (uint32_t)max_ret; r += FIN_THREADS) {
-            const size_t o = (size_t)b * max_ret + r;
-            if (r < keep) {
-                const uint64_t ck = final_to_cand(k[r]);
-                const uint32_t idx = key_anchor(ck);
-                out_boxes[o] = candidate_box(anchors, rb, b, N, idx, do_clip, hi_x, hi_y);
-                out_scores[o] = key_score(ck);
-                out_labels[o] = (int32_t)key_class(ck);
-                if (out_keep) out_keep[o] = (int32_t)idx;
-            } else {
-                out_boxes[o] = make_float4(0.f, 0.f, 0.f, 0.f);
-                out_scores[o] = 0.0f;
-                out_labels[o] = 0;
-                if (out_keep) out_keep[o] = -1;
-            }
-        }
+        emit_detections(k, keep, b, anchors, rb, N, do_clip, hi_x, hi_y, max_ret, out_boxes, out_scores, out_labels, out_keep);
     };
     if (out_count && tid == 0) out_count[b] = (int32_t)keep;
 
     if ((uint32_t)max_ret <= FIN_CHUNK) {
         // the list goes through LDS in batches of lds_keys keys: the 128 best so far are carried in chunk 0
-        const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = FIN_THREADS / WAVE;
         uint32_t carry = 0;
         for (uint32_t base = 0; base < n || base == 0;) {
             const uint32_t take = min(n - base, lds_keys - carry);
@@ -1425,33 +1488,7 @@ __device__ __forceinline__ void finalize_image(
             for (uint32_t i = carry + tid; i < nchunks * FIN_CHUNK; i += FIN_THREADS) s_keys[i] = i < cnt ? gk[base + i - carry] : ~0ull;
             __syncthreads();
             ODBOX_LAP(stp, 57, tid == 0);                     // keys in LDS
-            for (uint32_t c = wave; c < nchunks; c += nwaves) {
-                uint64_t k[2];
-                uint64_t *ch = s_keys + c * FIN_CHUNK;
-                k[0] = ch[lane * 2];
-                k[1] = ch[lane * 2 + 1];
-                wave_sort_regs<2>(k, lane);
-                ch[lane * 2] = k[0];
-                ch[lane * 2 + 1] = k[1];
-            }
-            __syncthreads();
-            for (uint32_t stride = 1; stride < nchunks; stride <<= 1) {
-                for (uint32_t c = wave * 2 * stride; c + stride < nchunks; c += nwaves * 2 * stride) {
-                    uint64_t *lo = s_keys + c * FIN_CHUNK;
-                    const uint64_t *hi = s_keys + (c + stride) * FIN_CHUNK;
-                    uint64_t k[2];
-#pragma unroll
-                    for (uint32_t s0 = 0; s0 < 2; ++s0) {
-                        const uint32_t e = lane * 2 + s0;
-                        const uint64_t x = lo[e], y = hi[FIN_CHUNK - 1 - e];
-                        k[s0] = x < y ? x : y;
-                    }
-                    wave_sort_regs<2, true>(k, lane);
-                    lo[lane * 2] = k[0];
-                    lo[lane * 2 + 1] = k[1];
-                }
-                __syncthreads();
-            }
+            best128_of_chunks(s_keys, nchunks, tid);
             base += take;
             carry = FIN_CHUNK;
             ODBOX_LAP(stp, 58, tid == 0);                     // chunk sorts and merges
@@ -1499,9 +1536,360 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
     if (pass != 1) return;
     __syncthreads();                                          // everybody has read state[b] and is done with the LDS keys
     if (tid == 0) state[b] = again ? 0 : 1;
+    if (again && tid == 0) atomicAdd(coop_count + 1, 1);      // (coop_count: pass 2's; behind it the number of images pass 2 has to do)
     if (again)
         partition_image(s_fin, b, gridDim.x * (uint32_t)C, cand_count, keys_in, keys_out, cand_stride, C, pre_nms_topk,
                         seg_start, coop_count, coop_list, 2, 0u, state, fin_count);
+}
+
+// ------------------------------------------------------------------------------------------
+// Pass 1 in ONE launch (round 3): tier selection, class partition, per-class greedy NMS and the final top-k of one
+// image by one block, everything between the candidate list and the detections in LDS and registers.  As three
+// kernels pass 1 cost 4 + 12 + 7 us plus two kernel boundaries on the configs[4] share, nearly all of it latency:
+// global round trips between phases (keys out and in again, segment starts, kept keys through atomically reserved
+// slots) and 5 760 one-segment waves that each pay a launch slot, a key load and a box gather for nine candidates.
+// Here the tier (at most TT_CAP candidates) is laid out densely in class order, ONE CANDIDATE PER LANE:
+//   * positions 64 w .. 64 w + 63 are window w, one window per wave (16 waves);
+//   * every lane ranks its key inside its class segment (keys are distinct: the number of smaller keys of the
+//     segment is the sorted place), so the array is in visiting order (class asc, score desc, anchor asc);
+//   * all boxes are gathered at once, one per lane, and published in LDS;
+//   * a window resolves ALL its class segments together: a lane's leader is the first live lane of its segment (a
+//     find-first-set on the live mask under the lane's segment mask); the leader is kept, the other live lanes of
+//     the segment are tested against its box (an LDS read at a per-lane index) and leave when they overlap it or
+//     when max_ret boxes of their class have been kept before them (bndbox.py:172) -- as many trips as the longest
+//     kept list among the window's segments, not their sum;
+//   * a segment that continues from earlier windows (at most one per window: the layout is dense) is done in rounds,
+//     chunk r of every such segment in round r: after each round the lanes of the later chunks are tested against
+//     the boxes the chunk kept (LDS reads), then resolve in their own round.  With segments of nine candidates on
+//     average there are two rounds; one class of 800 takes thirteen.  Same visiting order, same test, same cap as
+//     nms_wave_segment / nms_coop_block: identical keep-lists.
+// The kept lanes pack their keys, turned into final keys, at the front of the array and the block's 128 best are
+// sorted out as in finalize_image.
+// THE LADDER.  Any tier that keeps max_ret boxes gives the exact detections, and the block's cost grows with the
+// tier, so the first attempt takes a quarter of the largest tier (factor 8: the best 2 max_ret candidates).  If that
+// keeps too few, the second attempt's size comes from the first one's survival rate (1.5 max_ret / rate, at least
+// twice the first, at most the largest tier); an image whose rate says that even the largest tier will not hold
+// max_ret survivors, whose tier does not fit (more than TT_CAP keys with the ties at its edge) or whose list the
+// pre-NMS top-k cuts is partitioned for pass 2 right here, like the pass-1 final kernel does it.  state[b] records
+// which attempt finished the image (0: pass 2).  On the configs[4] share: 18.7 us against 4 + 12 + 7 us and two
+// boundaries, one call 207 -> 197 us on one box (tools/exp_nms_single.py --fused 0 / 1).
+// ------------------------------------------------------------------------------------------
+#ifndef ODBOX_TT_THREADS
+#define ODBOX_TT_THREADS 1024
+#endif
+#ifndef ODBOX_TIER_FIRST_DIV
+#define ODBOX_TIER_FIRST_DIV 4                // first rung of the fused block's tier ladder = largest tier / this
+#endif
+constexpr int TT_THREADS = ODBOX_TT_THREADS;                          // 1024: one window per wave; 512: two
+constexpr uint32_t TT_CAP = 1024;
+constexpr int TT_WPW = (int)TT_CAP / TT_THREADS;                      // windows per wave
+constexpr int TT_REG = PART_REG * PART_THREADS / TT_THREADS;          // keys per thread: the lists partition_image holds in registers
+constexpr int TT_WAVES = TT_THREADS / WAVE;
+constexpr uint32_t TT_WINDOWS = TT_CAP / WAVE;
+constexpr size_t TT_REGION = (size_t)TT_CAP * sizeof(float4);         // tier histogram / keys + class histogram / boxes / final keys
+__host__ __device__ constexpr size_t tier_tail_lds(int C)             // region, segment starts [C + 1], kept masks [2][windows], scratch
+{
+    return TT_REGION + (((size_t)(C + 1) * sizeof(int) + 15) & ~(size_t)15) + 2 * TT_WINDOWS * 8 + 64 * sizeof(int);
+}
+static_assert(PART_THREADS == FIN_THREADS && TT_THREADS >= PART_THREADS && TT_WPW >= 1 && TT_WPW * TT_THREADS == (int)TT_CAP,
+              "the block's first PART_THREADS threads also partition for pass 2");
+static_assert(tier_tail_lds(90) <= TAIL_LDS_FIT, "the fused pass-1 block does not fit beside a scan");
+static_assert((TIER_BUCKETS + 2) * sizeof(int) <= TT_REGION / 2, "tier histogram in the lower half of the region");
+
+__global__ __launch_bounds__(TT_THREADS) void tier_tail_kernel(
+    const float4 *__restrict__ anchors, const BoxSrc rb, int N, int C, int do_clip, float hi_x, float hi_y, NmsThr thr,
+    int max_ret, const int *__restrict__ cand_count, uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out,
+    uint32_t cand_stride, uint32_t pre_nms_topk, uint32_t tier_k, uint32_t tier_first, int *__restrict__ seg_start,
+    int *__restrict__ coop_count2, int *__restrict__ coop_list, int *__restrict__ state, int *__restrict__ fin_count, float4 *__restrict__ out_boxes,
+    float *__restrict__ out_scores, int32_t *__restrict__ out_labels, int32_t *__restrict__ out_keep,
+    int32_t *__restrict__ out_count)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_tt[];
+    uint64_t *s_keys = reinterpret_cast<uint64_t *>(s_tt);                          // [TT_CAP]   lower half of the region
+    int *s_tier = reinterpret_cast<int *>(s_tt);                                    // [TIER_BUCKETS + 2], before the keys
+    int *s_hist = reinterpret_cast<int *>(s_tt + TT_REGION / 2);                    // [copies][C], upper half, until the scatter
+    float4 *s_box = reinterpret_cast<float4 *>(s_tt);                               // [TT_CAP]   the whole region, after the sort
+    int *s_start = reinterpret_cast<int *>(s_tt + TT_REGION);                       // [C + 1]
+    unsigned long long *s_keptmask = reinterpret_cast<unsigned long long *>(s_tt + TT_REGION + (((size_t)(C + 1) * sizeof(int) + 15) & ~(size_t)15));
+    int *s_misc = reinterpret_cast<int *>(s_keptmask + 2 * TT_WINDOWS);             // [0..31] scan scratch, [32] rounds, [33] kept
+    const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const int copies = part_copies(C);
+    const uint32_t cmax = (uint32_t)C - 1u;
+
+    Stamps stp;
+    const uint32_t M_all = min((uint32_t)cand_count[b * CNT_STRIDE], cand_stride);
+    ODBOX_LAP(stp, 40, tid == 0);                             // count loaded
+    // block-uniform: lists the pre-NMS top-k cuts, or longer than the block's registers, are pass 2's whole
+    bool again = (pre_nms_topk != 0u && M_all > pre_nms_topk) || M_all > (uint32_t)(TT_REG * TT_THREADS);
+    // The tier ladder: the first attempt takes a SMALL tier (tier_first candidates: a quarter of the largest); if it keeps
+    // max_ret boxes they are the image's detections (any tier that does is exact).  If not, the next attempt's size is
+    // read off the first one's survival rate -- 1.5 max_ret / (kept / tier) -- and an image whose rate says that even the
+    // largest tier will not do goes to pass 2 at once.  Every test below is block-uniform.
+    uint32_t tk = min(tier_first, tier_k);
+    int rung = 1;                                             // state[b]: 0 = left to pass 2, else the attempt that finished the image
+    while (!again) {
+        uint32_t M = M_all;
+        bool whole = false;
+        uint32_t total_kept = 0;
+        const uint64_t *in = keys_in + (size_t)b * cand_stride;
+        uint64_t kreg[TT_REG];
+#pragma unroll
+        for (int r = 0; r < TT_REG; ++r) {
+            const uint32_t i = tid + (uint32_t)r * TT_THREADS;
+            kreg[r] = i < M ? in[i] : ~0ull;
+        }
+        whole = M <= tk;
+        ODBOX_LAP(stp, 41, tid == 0);                         // keys loaded
+        if (!whole) M = tier_select<TT_THREADS, TT_REG>(kreg, M, tk, s_tier, s_misc, tid);
+        ODBOX_LAP(stp, 42, tid == 0);                         // tier selected
+        again = M > TT_CAP;                                   // (a run of equal scores at the tier's edge)
+        if (again) break;
+        {
+            __syncthreads();                                  // the tier histogram has been read by everybody
+            // ---- class histogram, dense segment starts, scatter into LDS ------------------------------------
+            for (int c = tid; c < copies * C; c += TT_THREADS) s_hist[c] = 0;
+            __syncthreads();
+            int *my_hist = s_hist + (int)(tid & (uint32_t)(copies - 1)) * C;
+#pragma unroll
+            for (int r = 0; r < TT_REG; ++r)
+                if (kreg[r] != ~0ull) atomicAdd(&my_hist[min(key_class(kreg[r]), cmax)], 1);
+            __syncthreads();
+            const int chunk = (C + TT_THREADS - 1) / TT_THREADS;
+            const int c0 = min((int)tid * chunk, C), c1 = min(c0 + chunk, C);
+            int local = 0;
+            for (int c = c0; c < c1; ++c)
+                for (int k = 0; k < copies; ++k) local += s_hist[k * C + c];
+            int incl = local;
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) {
+                const int v = __shfl_up(incl, off);
+                if ((int)lane >= off) incl += v;
+            }
+            if (lane == 63u) s_misc[wave] = incl;
+            if (tid == 0) {
+                s_misc[32] = 0;
+                s_misc[33] = 0;
+            }
+            __syncthreads();
+            int run = incl - local;
+            for (uint32_t w = 0; w < wave; ++w) run += s_misc[w];
+            for (int c = c0; c < c1; ++c) {
+                s_start[c] = run;
+                int cnt = 0;
+                for (int k = 0; k < copies; ++k) {            // each copy becomes the scatter cursor of its lanes
+                    const int n = s_hist[k * C + c];
+                    s_hist[k * C + c] = run + cnt;
+                    cnt += n;
+                }
+                run += cnt;
+            }
+            if (tid == 0) s_start[C] = (int)M;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < TT_REG; ++r)
+                if (kreg[r] != ~0ull) {
+                    const uint32_t at = (uint32_t)atomicAdd(&my_hist[min(key_class(kreg[r]), cmax)], 1);
+                    if (at < TT_CAP) s_keys[at] = kreg[r];
+                }
+            __syncthreads();
+            ODBOX_LAP(stp, 43, tid == 0);                     // class histogram, starts, scatter
+        }
+        // ---- one candidate per lane: position p = tid + TT_THREADS h in the class-ordered array --------------------
+        uint64_t key[TT_WPW];
+        uint32_t seg_s[TT_WPW], seg_e[TT_WPW], place[TT_WPW];
+        bool valid[TT_WPW];
+#pragma unroll
+        for (int h = 0; h < TT_WPW; ++h) {
+            const uint32_t p = tid + (uint32_t)h * TT_THREADS;
+            valid[h] = p < M;
+            key[h] = valid[h] ? s_keys[p] : ~0ull;
+            const uint32_t c = min(key_class(key[h]), cmax);
+            seg_s[h] = valid[h] ? min((uint32_t)s_start[c], M) : 0u;
+            seg_e[h] = valid[h] ? min((uint32_t)s_start[c + 1u], M) : 0u;
+            // (four reads in flight per trip; a read past the segment's end stays inside the array and is not counted)
+            uint32_t r = 0;
+            for (uint32_t j = seg_s[h]; j < seg_e[h]; j += 4u) {
+                uint64_t kk[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) kk[u] = s_keys[min(j + u, TT_CAP - 1u)];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) r += (j + u < seg_e[h] && kk[u] < key[h]) ? 1u : 0u;
+            }
+            place[h] = min(seg_s[h] + r, TT_CAP - 1u);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < TT_WPW; ++h)
+            if (valid[h]) s_keys[place[h]] = key[h];
+        __syncthreads();
+        ODBOX_LAP(stp, 44, tid == 0);                         // rank sort
+        float4 nb[TT_WPW];
+        float area[TT_WPW];
+        uint32_t cls[TT_WPW], q[TT_WPW], q_in[TT_WPW];
+        unsigned long long segm[TT_WPW];
+        int kcnt[TT_WPW];
+        bool dead[TT_WPW], kept[TT_WPW];
+#pragma unroll
+        for (int h = 0; h < TT_WPW; ++h) {
+            const uint32_t p = tid + (uint32_t)h * TT_THREADS;
+            key[h] = valid[h] ? s_keys[p] : ~0ull;
+            cls[h] = min(key_class(key[h]), cmax);
+            nb[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            area[h] = 0.0f;
+            if (valid[h]) {
+                const float4 v = candidate_box(anchors, rb, b, N, key_anchor(key[h]), do_clip, hi_x, hi_y);
+                nb[h] = make_float4(fminf(v.x, v.z), fminf(v.y, v.w), fmaxf(v.x, v.z), fmaxf(v.y, v.w));
+                area[h] = (nb[h].w - nb[h].y) * (nb[h].z - nb[h].x);
+            }
+            // the segment that comes in from earlier windows, if any, holds lane 0 of the window; its chunk index
+            // here is the number of windows back to its start
+            const uint32_t w = wave + (uint32_t)h * TT_WAVES;
+            seg_s[h] = valid[h] ? min((uint32_t)s_start[cls[h]], M) : 0u;
+            seg_e[h] = valid[h] ? min((uint32_t)s_start[cls[h] + 1u], M) : 0u;
+            {   // the lanes of this window that hold my class segment (contiguous: the array is in class order)
+                const uint32_t w0 = w * WAVE;
+                const uint32_t a = seg_s[h] > w0 ? seg_s[h] - w0 : 0u;
+                const uint32_t e = seg_e[h] > w0 ? min(seg_e[h] - w0, (uint32_t)WAVE) : 0u;
+                segm[h] = (e >= (uint32_t)WAVE ? ~0ull : (1ull << e) - 1ull) & ~((1ull << min(a, 63u)) - 1ull);
+                if (!valid[h]) segm[h] = 0ull;
+            }
+            const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_s[h]);
+            const uint32_t c_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)cls[h]);
+            const bool has_in = (w * WAVE < M) && s0 < w * WAVE;            // wave-uniform
+            q_in[h] = has_in ? w - (s0 >> 6) : 0u;
+            q[h] = (has_in && cls[h] == c_first) ? q_in[h] : 0u;
+            kcnt[h] = 0;
+            dead[h] = !valid[h];
+            kept[h] = false;
+            if (lane == 0 && q_in[h] != 0u) atomicMax(&s_misc[32], (int)q_in[h]);
+        }
+        __syncthreads();                                      // every sorted key has been read: the region takes the boxes
+#pragma unroll
+        for (int h = 0; h < TT_WPW; ++h) s_box[tid + (uint32_t)h * TT_THREADS] = nb[h];
+        __syncthreads();
+        ODBOX_LAP(stp, 45, tid == 0);                         // boxes gathered and published
+        const uint32_t rounds = (uint32_t)s_misc[32] + 1u;   // block-uniform
+        for (uint32_t r = 0; r < rounds; ++r) {
+            // every class segment of a window at once: a lane's LEADER is the first live lane of its segment; the leader
+            // is kept, the others are tested against its box (an LDS read at a per-lane index) -- as many trips as the
+            // longest kept list among the window's segments, not their sum.  Both windows of the wave share the loop.
+            unsigned long long alive[TT_WPW], any = 0ull;
+            bool lead_r[TT_WPW];
+#pragma unroll
+            for (int h = 0; h < TT_WPW; ++h) {
+                lead_r[h] = false;
+                alive[h] = __ballot(!dead[h] && q[h] == r);
+                any |= alive[h];
+            }
+            while (any != 0ull) {
+                any = 0ull;
+#pragma unroll
+                for (int h = 0; h < TT_WPW; ++h) {
+                    if (alive[h] == 0ull) continue;           // wave-uniform
+                    const uint32_t w = wave + (uint32_t)h * TT_WAVES;
+                    const unsigned long long my = alive[h] & segm[h];
+                    const bool act = ((alive[h] >> lane) & 1ull) != 0ull;
+                    const uint32_t leader = my != 0ull ? (uint32_t)(__ffsll(my) - 1) : lane;
+                    const float4 jb = s_box[w * WAVE + leader];
+                    const float ja = (jb.w - jb.y) * (jb.z - jb.x);
+                    bool hit = false, band = false;
+                    nms_test(nb[h], area[h], jb.x, jb.y, jb.z, jb.w, ja, thr, hit, band);
+                    if (__ballot(act && band && !hit) != 0ull)            // wave-uniform, practically never
+                        if (nms_suppresses_exact(nb[h], area[h], jb.x, jb.y, jb.z, jb.w, ja, thr)) hit = true;
+                    const bool lead = act && leader == lane;
+                    kcnt[h] += act ? 1 : 0;                   // one more kept box of my class
+                    lead_r[h] = lead_r[h] || lead;
+                    alive[h] = __ballot(act && !lead && !hit && kcnt[h] < max_ret);
+                    any |= alive[h];
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < TT_WPW; ++h) {
+                const uint32_t w = wave + (uint32_t)h * TT_WAVES;
+                kept[h] = kept[h] || lead_r[h];
+                const unsigned long long keptm = __ballot(lead_r[h]);
+                if (lane == 0) s_keptmask[(r & 1u) * TT_WINDOWS + w] = keptm;
+            }
+            if (r + 1u >= rounds) break;
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < TT_WPW; ++h) {
+                if (q_in[h] <= r) continue;                   // wave-uniform
+                // chunk r of the segment that comes in lives in window src: its lanes there run from the segment's
+                // start (r == 0) or from lane 0 to the window's end
+                const uint32_t w = wave + (uint32_t)h * TT_WAVES;
+                const uint32_t src = w - q_in[h] + r;
+                const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_s[h]);
+                const uint32_t first = s0 > src * WAVE ? s0 - src * WAVE : 0u;
+                unsigned long long km = s_keptmask[(r & 1u) * TT_WINDOWS + src];
+                km = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(km >> 32)) << 32) |
+                     (unsigned int)__builtin_amdgcn_readfirstlane((int)km);
+                km &= ~((1ull << first) - 1ull);
+                const bool mine = q[h] == q_in[h] && !dead[h];
+                bool hit = false;
+                for (; km != 0ull; km &= km - 1ull) {
+                    const int j = __ffsll(km) - 1;
+                    const float4 jb = s_box[src * WAVE + (uint32_t)j];
+                    const float ja = (jb.w - jb.y) * (jb.z - jb.x);
+                    if (nms_suppresses(nb[h], area[h], jb.x, jb.y, jb.z, jb.w, ja, thr)) hit = true;
+                    kcnt[h] += q[h] == q_in[h] ? 1 : 0;
+                }
+                if (mine && (hit || kcnt[h] >= max_ret)) dead[h] = true;
+            }
+        }
+        ODBOX_LAP(stp, 46, lane == 0);                        // rounds (per wave)
+        // ---- final top-k: the kept lanes' keys in final order, packed (any order: they are sorted next) in place of
+        // the boxes, so that the sort below sees ceil(kept / 128) chunks, not ceil(tier / 128)
+        uint32_t slot[TT_WPW];
+        {
+            unsigned long long km[TT_WPW];
+            uint32_t n0 = 0;
+#pragma unroll
+            for (int h = 0; h < TT_WPW; ++h) {
+                km[h] = __ballot(kept[h]);
+                slot[h] = n0 + (uint32_t)__popcll(km[h] & ((1ull << lane) - 1ull));
+                n0 += (uint32_t)__popcll(km[h]);
+            }
+            int base = 0;
+            if (lane == 0 && n0 != 0u) base = atomicAdd(&s_misc[33], (int)n0);
+            base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+            for (int h = 0; h < TT_WPW; ++h) slot[h] += (uint32_t)base;
+        }
+        __syncthreads();                                      // every box has been read, every wave has its slots
+        total_kept = (uint32_t)s_misc[33];
+        const uint32_t nchunks = max((total_kept + FIN_CHUNK - 1) / FIN_CHUNK, 1u);
+        for (uint32_t p = total_kept + tid; p < nchunks * FIN_CHUNK; p += TT_THREADS) s_keys[p] = ~0ull;
+#pragma unroll
+        for (int h = 0; h < TT_WPW; ++h)
+            if (kept[h] && slot[h] < TT_CAP) s_keys[slot[h]] = cand_to_final(key[h]);
+        __syncthreads();
+        ODBOX_LAP(stp, 47, tid == 0);                         // final keys in LDS (waits for the slowest wave)
+        if (whole || total_kept >= (uint32_t)max_ret) {
+            best128_of_chunks<TT_WAVES>(s_keys, nchunks, tid);
+            ODBOX_LAP(stp, 48, tid == 0);                     // chunk sorts and merges
+            const uint32_t keep = min(total_kept, (uint32_t)max_ret);
+            if (out_count && tid == 0) out_count[b] = (int32_t)keep;
+            emit_detections(s_keys, keep, b, anchors, rb, N, do_clip, hi_x, hi_y, max_ret, out_boxes, out_scores, out_labels, out_keep);
+            ODBOX_LAP(stp, 49, tid == 0);                     // winners decoded and stored
+            break;
+        }
+        // not enough survivors: the tier that can be expected to hold max_ret of them, with half as many again to spare
+        const uint64_t want = ((uint64_t)max_ret * M * 3u) / (2u * max(total_kept, 1u)) + 1u;
+        again = tk >= tier_k || want > (uint64_t)tier_k;
+        if (again) break;
+        tk = min(tier_k, max((uint32_t)want, 2u * tk));
+        ++rung;
+        __syncthreads();                                      // the LDS starts over
+    }
+    if (tid == 0) state[b] = again ? 0 : rung;
+    if (again && tid == 0) atomicAdd(coop_count2 + 1, 1);     // the number of images pass 2 has to do
+    if (again) {
+        __syncthreads();                                      // the LDS is free
+        if (tid >= (uint32_t)PART_THREADS) return;            // (whole waves; waves that have ended do not count at a barrier)
+        partition_image(s_tt, b, gridDim.x * (uint32_t)C, cand_count, keys_in, keys_out, cand_stride, C, pre_nms_topk,
+                        seg_start, coop_count2, coop_list, 2, 0u, state, fin_count);
+    }
 }
 
 // kernel 3: the first coop_blocks blocks take the big segments cooperatively (they start first, so
@@ -1526,7 +1914,7 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
     const int *__restrict__ coop_count, const int *__restrict__ coop_list, uint32_t coop_blocks,
     int *fin_count, uint64_t *fin_keys, uint32_t fin_stride,
     uint32_t total_segments, int waves_per_block, uint32_t per_wave_bytes, uint32_t sort_cap, uint32_t kept_alias,
-    const int *__restrict__ done, FinalArgs fa, hdr_word *hdr, uint32_t dbg)
+    const int *__restrict__ done, FinalArgs fa, hdr_word *hdr, uint32_t vblocks, uint32_t dbg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     ODBOX_NO_EXPERIMENTS(dbg);
@@ -1546,6 +1934,8 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
         __shared__ int s_owner[NMS_WAVES];
         __shared__ int s_last;
         if (hdr && blockIdx.x == 0 && threadIdx.x == 0) hdr[0] = hdr[0] + 1ull;      // the call's last kernel: next epoch (see wait_ready)
+        // no image was left to pass 2 (the usual case): every block leaves on one scalar load
+        if (coop_count[1] == 0) return;
         // called by every thread of the block with block-uniform arguments
         auto segments_done = [&](uint32_t b, int count) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's kept keys have left it
@@ -1567,24 +1957,28 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
                                fin_keys, fin_stride, fa.lds_keys, fa.out_boxes, fa.out_scores, fa.out_labels, fa.out_keep, fa.out_count);
             __syncthreads();                                       // s_last and the LDS are free again
         };
-        if (blockIdx.x < coop_blocks) {
-            nms_coop_block(s_raw, blockIdx.x, coop_blocks, anchors, rb, N, C, do_clip, hi_x, hi_y, thr, max_ret, cand_keys,
-                           cand_stride, seg_start, coop_count, coop_list, total_segments, fin_count, fin_keys, fin_stride, true,
-                           [&](uint32_t b) { segments_done(b, 1); });
-            return;
-        }
-        const int owner = nms_wave_segment(s_raw, blockIdx.x - coop_blocks, anchors, rb, N, C, do_clip, hi_x, hi_y, thr, max_ret,
-                                           cand_keys, cand_stride, seg_start, fin_count, fin_keys, fin_stride, total_segments,
-                                           waves_per_block, per_wave_bytes, sort_cap, coop_blocks != 0, kept_alias != 0, done, dbg);
-        if ((threadIdx.x & 63u) == 0u) s_owner[threadIdx.x >> 6] = owner;
-        __syncthreads();
-        // the block's segments are consecutive, so the waves that finished segments of one image are neighbours
-        for (int w = 0; w < waves_per_block;) {
-            const int ob = s_owner[w];
-            int w2 = w;
-            while (w2 < waves_per_block && s_owner[w2] == ob) ++w2;
-            if (ob >= 0) segments_done((uint32_t)ob, w2 - w);
-            w = w2;
+        // The launch is a few blocks per CU that walk the block ids of the pass-1 geometry (vblocks of them).
+        for (uint32_t vb = blockIdx.x; vb < vblocks; vb += gridDim.x) {
+            if (vb < coop_blocks) {
+                nms_coop_block(s_raw, vb, coop_blocks, anchors, rb, N, C, do_clip, hi_x, hi_y, thr, max_ret, cand_keys,
+                               cand_stride, seg_start, coop_count, coop_list, total_segments, fin_count, fin_keys, fin_stride, true,
+                               [&](uint32_t b) { segments_done(b, 1); });
+                continue;
+            }
+            const int owner = nms_wave_segment(s_raw, vb - coop_blocks, anchors, rb, N, C, do_clip, hi_x, hi_y, thr, max_ret,
+                                               cand_keys, cand_stride, seg_start, fin_count, fin_keys, fin_stride, total_segments,
+                                               waves_per_block, per_wave_bytes, sort_cap, coop_blocks != 0, kept_alias != 0, done, dbg);
+            if ((threadIdx.x & 63u) == 0u) s_owner[threadIdx.x >> 6] = owner;
+            __syncthreads();
+            // the block's segments are consecutive, so the waves that finished segments of one image are neighbours
+            for (int w = 0; w < waves_per_block;) {
+                const int ob = s_owner[w];
+                int w2 = w;
+                while (w2 < waves_per_block && s_owner[w2] == ob) ++w2;
+                if (ob >= 0) segments_done((uint32_t)ob, w2 - w);
+                w = w2;
+            }
+            __syncthreads();                                       // s_owner is free again
         }
     }
 }
@@ -1827,6 +2221,12 @@ int odbox_set_nms_tier(int factor)
     return g_tier_factor.exchange(factor, std::memory_order_relaxed);
 }
 
+int odbox_set_nms_fused_tail(int on)
+{
+    if (on != 0 && on != 1) return fail(ODBOX_EINVAL, "odbox_set_nms_fused_tail: %d (0 or 1)", on);
+    return g_fused_tail.exchange(on, std::memory_order_relaxed);
+}
+
 size_t odbox_decode_nms_workspace(int B, int N, int C, int max_ret, int pre_nms_topk)
 {
     (void)pre_nms_topk;
@@ -1960,9 +2360,34 @@ int decode_nms_impl(const char *who, const float *anchors, const void *regress_o
     if (int r4 = allow_lds(finalize_kernel, fin_part_lds)) return r4;
     if (int r5 = allow_lds(nms_kernel<true>, nms2_lds)) return r5;
 
+    // pass 2: four blocks per CU walk the pass-1 block ids (see nms_kernel<true>; a batch whose every image falls through:
+    // 628 / 336 / 270 us with 64 / 256 / 1024 blocks, 280 us with one block per id; the empty launch costs the same)
+    const uint32_t nms2_cap = 4u * (uint32_t)device_cu_count();
+    const uint32_t nms2_grid = nms_grid < nms2_cap ? (uint32_t)nms_grid : nms2_cap;
     const FinalArgs fa = {(uint32_t)fin_keys_lds, (float4 *)out_boxes, out_scores, out_labels, out_keep_anchor, out_count};
     const uint32_t nms_dbg = (uint32_t)(tuning_env("ODBOX_NMS_DBG") ? atoi(tuning_env("ODBOX_NMS_DBG")) : 0);
     const int kpass = passes == 1 ? 0 : 1;                         // 0: one plain pass (no tier, no per-image state)
+    // Pass 1 as ONE launch (tier_tail_kernel): when there is a tier, it leaves room in the block's TT_CAP lanes for the
+    // ties at its edge, the final top-k is the 128-key form and the class histogram fits beside the keys
+    const bool fused = g_fused_tail.load(std::memory_order_relaxed) != 0 && passes == 2 && max_ret <= (int)FIN_CHUNK &&
+                       (uint64_t)tier_k + tier_k / 8 <= TT_CAP && (size_t)part_copies(C) * C * sizeof(int) <= TT_REGION / 2;
+    if (fused) {
+        // the ladder's first rung: a quarter of the largest tier (factor 8: the best 2 * max_ret candidates)
+        const uint32_t tier_first = tier_factor >= 2 * ODBOX_TIER_FIRST_DIV ? tier_k / ODBOX_TIER_FIRST_DIV : tier_k;
+        const size_t tt_lds = tier_tail_lds(C) > part_lds ? tier_tail_lds(C) : part_lds;      // (the block also partitions for pass 2)
+        if (int r6 = allow_lds(tier_tail_kernel, tt_lds)) return r6;
+        hipLaunchKernelGGL(tier_tail_kernel, dim3(B), dim3(TT_THREADS), tt_lds, st, (const float4 *)anchors, rb, N, C, do_clip,
+                           hi_x, hi_y, nms_thr, max_ret, (const int *)cand_count, keys_a, keys_b, L.cand_stride,
+                           (uint32_t)pre_nms_topk, tier_k, tier_first, seg_start, coop_count + 1, coop_list, state, fin_count,
+                           (float4 *)out_boxes, out_scores, out_labels, out_keep_anchor, out_count);
+        if (int r6 = launch_status("tier_tail")) return r6;
+        hipLaunchKernelGGL(nms_kernel<true>, dim3(nms2_grid), dim3(waves * WAVE), nms2_lds, st, (const float4 *)anchors,
+                           rb, N, C, do_clip, hi_x, hi_y, nms_thr, max_ret, nms_keys,
+                           L.cand_stride, seg_start, (const int *)(coop_count + 1), (const int *)coop_list, coop_blocks,
+                           fin_count, fin_keys, L.fin_stride, (uint32_t)segs, waves, (uint32_t)per_wave, sort_cap, kept_alias,
+                           (const int *)state, fa, hdr, (uint32_t)nms_grid, nms_dbg);
+        return launch_status("nms (pass 2)");
+    }
     // kernel 2: (pass 1) the tier; (plain pass) the pre-NMS top-k where it binds; then group by class (counting sort)
     hipLaunchKernelGGL(cand_partition_kernel, dim3(B), dim3(PART_THREADS), part_lds, st, cand_count, keys_a, keys_b,
                        L.cand_stride, C, (uint32_t)pre_nms_topk, seg_start, coop_count, coop_list, kpass, tier_k, state, fin_count);
@@ -1972,7 +2397,7 @@ int decode_nms_impl(const char *who, const float *anchors, const void *regress_o
                        rb, N, C, do_clip, hi_x, hi_y, nms_thr, max_ret, nms_keys,
                        L.cand_stride, seg_start, (const int *)coop_count, (const int *)coop_list, coop_blocks,
                        fin_count, fin_keys, L.fin_stride, (uint32_t)segs, waves, (uint32_t)per_wave, sort_cap, kept_alias,
-                       (const int *)nullptr, fa, (hdr_word *)nullptr, nms_dbg);
+                       (const int *)nullptr, fa, (hdr_word *)nullptr, (uint32_t)nms_grid, nms_dbg);
     if (int r3 = launch_status("nms")) return r3;
     // kernel 4: final order, top max_ret, zero padding; in pass 1 also the partition of pass 2 for the images that need it
     hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(FIN_THREADS), fin_part_lds, st, (const float4 *)anchors,
@@ -1984,11 +2409,11 @@ int decode_nms_impl(const char *who, const float *anchors, const void *regress_o
     if (int r4 = launch_status("finalize")) return r4;
     if (passes == 2) {
         // pass 2: the NMS of the images whose tier was not enough, with their final top-k in the same launch
-        hipLaunchKernelGGL(nms_kernel<true>, dim3((uint32_t)nms_grid), dim3(waves * WAVE), nms2_lds, st, (const float4 *)anchors,
+        hipLaunchKernelGGL(nms_kernel<true>, dim3(nms2_grid), dim3(waves * WAVE), nms2_lds, st, (const float4 *)anchors,
                            rb, N, C, do_clip, hi_x, hi_y, nms_thr, max_ret, nms_keys,
                            L.cand_stride, seg_start, (const int *)(coop_count + 1), (const int *)coop_list, coop_blocks,
                            fin_count, fin_keys, L.fin_stride, (uint32_t)segs, waves, (uint32_t)per_wave, sort_cap, kept_alias,
-                           (const int *)state, fa, hdr, nms_dbg);
+                           (const int *)state, fa, hdr, (uint32_t)nms_grid, nms_dbg);
         if (int r5 = launch_status("nms (pass 2)")) return r5;
     }
     return 0;

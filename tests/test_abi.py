@@ -208,6 +208,8 @@ def test_every_entry_rejects_bad_arguments_without_touching_the_gpu(lib):
     assert lib.odbox_set_output_policy(7) == -1 and b'odbox_set_output_policy' in lib.odbox_last_error()
     assert lib.odbox_set_nms_tier(0) == 8 and lib.odbox_set_nms_tier(8) == 0             # default 8, 0 = off
     assert lib.odbox_set_nms_tier(-1) == -1 and b'odbox_set_nms_tier' in lib.odbox_last_error()
+    assert lib.odbox_set_nms_fused_tail(0) == 1 and lib.odbox_set_nms_fused_tail(1) == 0  # default on
+    assert lib.odbox_set_nms_fused_tail(2) == -1 and b'odbox_set_nms_fused_tail' in lib.odbox_last_error()
     assert lib.odbox_set_output_policy(2) == 0 and lib.odbox_set_output_policy(0) == 2
     # which kernel a dense match+encode takes is host logic (odbox_match_encode_plan: 0 tiles, 1 streamed tiles, 2 sweep)
     assert lib.odbox_match_encode_plan(64, 10647, 20, 80, 1, 0) == 2               # AUTO, a label-stream shape: the sweep (AUTO is a function of the shape)

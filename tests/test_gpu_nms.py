@@ -530,3 +530,125 @@ def test_score_tier_and_its_fallback():
         masked[b, order[500:]] = 0
     got = BB.decode_and_nms(anchors_pile, regress, scores, (S, S), max_ret=max_ret, pre_nms_topk=500, return_keep=True)
     check(got, c_oracle.decode_nms(anchors_pile, regress, masked, (S, S), max_ret=max_ret, threads=4))
+
+
+def _one_class_pile(rng, N, C, sizes, S=160, quant=32):
+    """images whose candidates are split over the classes as `sizes` says (one tuple per image), many exact ties"""
+    B = len(sizes)
+    side = int(np.ceil(np.sqrt(N / 9)))
+    anchors = O.tile_anchors(O.base_anchors(32, (1, 2, .5)), side, side, 8)[:N]
+    regress = np.clip(rng.normal(0, 0.4, (B, N, 4)), -2, 2).astype(F)
+    scores = rng.uniform(0, 0.2, (B, N, C)).astype(F)
+    for b, per_class in enumerate(sizes):
+        perm = rng.permutation(N)
+        at = 0
+        for c, m in enumerate(per_class):
+            idx = perm[at:at + m]
+            at += m
+            scores[b, idx, c] = (np.floor((0.3 + 0.7 * rng.uniform(size=m)) * quant) / quant + 1 / (2 * quant)).astype(F)
+    return anchors, regress, scores
+
+
+@pytest.mark.parametrize('max_ret', [100, 7, 113])
+def test_fused_pass_one_block_against_the_separate_kernels_and_the_oracle(max_ret):
+    """Pass 1 as one launch (tier_tail_kernel: one candidate per lane, class segments walked inside 64-lane windows,
+    segments that cross windows in rounds) against the oracle and against the separate partition / NMS / final
+    kernels.  Images: (0) many short segments; (1) one class holds the whole tier (a chain of up to 16 windows);
+    (2) segments of 60-70 candidates, so that nearly every window boundary cuts one; (3) a few long segments beside
+    empty classes and singletons; (4) fewer candidates than a tier; (5) none; (6) the tier's edge inside a run of
+    equal scores that overflows the block (left to pass 2); (7) exactly a tier of one class."""
+    rng = np.random.default_rng(500 + max_ret)
+    N, C = 6000, 24
+    tier = 8 * max_ret
+    sizes = [
+        tuple(int(x) for x in rng.integers(20, 110, C)),
+        (0, 0, 0, 2500) + (0,) * (C - 4),
+        tuple(int(x) for x in rng.integers(60, 71, C)),
+        (300, 0, 1, 1, 0, 513, 64, 65, 0, 128, 129, 1) + (0,) * (C - 12),
+        tuple(int(x) for x in rng.integers(0, 4, C)),
+        (0,) * C,
+        (0,) * C,                                            # filled below
+        (tier,) + (0,) * (C - 1),
+    ]
+    anchors, regress, scores = _one_class_pile(rng, N, C, sizes)
+    idx = rng.permutation(N)[:3000]                          # image 6: 3 000 candidates at ONE score
+    scores[6, idx, rng.integers(0, C, 3000)] = F(0.5)
+    got = BB.decode_and_nms(anchors, regress, scores, (160, 160), max_ret=max_ret, return_keep=True)
+    want = c_oracle.decode_nms(anchors, regress, scores, (160, 160), max_ret=max_ret, threads=4)
+    check(got, want)
+    assert BB.set_nms_fused_tail(False) is True
+    try:
+        sep = BB.decode_and_nms(anchors, regress, scores, (160, 160), max_ret=max_ret, return_keep=True)
+    finally:
+        assert BB.set_nms_fused_tail(True) is False
+    for x, y in zip(got, sep):
+        assert torch.equal(x, y)
+    # small per-class caps inside the fused walk (bndbox.py:172: at most max_ret boxes per class)
+    for cap in (1, 2, 5):
+        check(BB.decode_and_nms(anchors, regress, scores, (160, 160), max_ret=cap, return_keep=True),
+              c_oracle.decode_nms(anchors, regress, scores, (160, 160), max_ret=cap, threads=4))
+
+
+def test_the_whole_file_holds_with_the_separate_kernels_too():
+    """The cases above run with the fused pass-1 block wherever it applies (the default); the same inputs through
+    the separate kernels: one representative of each family."""
+    assert BB.set_nms_fused_tail(False) is True
+    try:
+        test_decode_nms_random(3, 1000, 90, 400, 100)
+        test_score_tier_and_its_fallback()
+        test_cfg5_slice_full_anchor_set()
+    finally:
+        assert BB.set_nms_fused_tail(True) is False
+
+
+def test_tier_ladder_of_the_fused_block():
+    """The fused pass-1 block starts with a quarter of the largest tier and, when that keeps too few boxes, sizes its
+    second attempt from the first one's survival rate (or leaves the image to pass 2 when the rate says no tier will
+    do).  One batch with an image for every rung, max_ret = 50 (rungs: 100 candidates, then up to 400):
+    (0) far-apart boxes: the first rung keeps enough; (1) every box three times: a third survives, the second rung
+    (about 230 candidates) is needed; (2) every box twelve times: one in twelve survives, pass 2 on the whole list;
+    (3) eight copies each, few boxes: not even the whole list holds max_ret detections."""
+    rng = np.random.default_rng(2024)
+    B, N, C, max_ret = 4, 5400, 5, 50
+    side = int(np.ceil(np.sqrt(N / 9)))
+    anchors = O.tile_anchors(O.base_anchors(12, (1, 2, .5)), side, side, 16)[:N]     # small boxes on a wide grid
+    regress = np.zeros((B, N, 4), F)
+    scores = rng.uniform(0, 0.2, (B, N, C)).astype(F)
+    S = 16 * side
+
+    def copies(b, n_boxes, k):
+        """n_boxes distinct anchors (one aspect ratio each, so that they do not overlap), each k times"""
+        base = rng.choice(N // 9, n_boxes, replace=False) * 9
+        clones = rng.choice(np.setdiff1d(np.arange(N), base), n_boxes * (k - 1), replace=False) if k > 1 else np.zeros(0, int)
+        idx = np.concatenate([base, clones]).astype(int)
+        src = np.concatenate([base, np.repeat(base, k - 1)]).astype(int)
+        return idx, src
+
+    local_anchors = np.broadcast_to(anchors, (B, N, 4)).copy()
+    for b, (n_boxes, k) in enumerate(((500, 1), (300, 3), (150, 12), (5, 8))):
+        idx, src = copies(b, n_boxes, k)
+        local_anchors[b, idx] = anchors[src]
+        # the copies of a box score just below it, so a tier holds whole groups: 1 / k of its candidates survive
+        group = (0.35 + 0.6 * rng.uniform(size=n_boxes)).astype(F)
+        sc = np.concatenate([group, np.repeat(group, k - 1) - np.tile(np.arange(1, k), n_boxes).astype(F) * F(2.0 ** -14)])
+        scores[b, idx, rng.integers(0, C, 1) if k > 1 else rng.integers(0, C, len(idx))] = sc.astype(F)
+    # per-image anchors: hand over decoded boxes (the plain nms entry), clipped like decode_and_nms would
+    boxes = O.clip_boxes(local_anchors, (S, S))
+    got = BB.nms(boxes, scores, max_ret=max_ret, return_keep=True)
+    want = c_oracle.decode_nms(None, boxes, scores, (S, S), do_clip=False, max_ret=max_ret, threads=4)
+    check(got, want)
+    cnt = cpu(got[4])
+    assert cnt[0] == max_ret and cnt[1] == max_ret and cnt[2] == max_ret and 0 < cnt[3] < max_ret
+    # which rung finished each image: the block leaves it in the workspace's per-image state words (behind the epoch
+    # line and the two counter lines per image; 0 = left to pass 2)
+    lib = _lib.load()
+    ws = _lib.workspace('decode_nms', _lib.require_gpu(), lib.odbox_decode_nms_workspace(B, N, C, max_ret, 0))
+    state = ws[256 + 2 * B * 64 * 4:][:4 * B].view(torch.int32).cpu().tolist()
+    assert state == [1, 2, 0, 1], state            # (image 3: fewer candidates than the first rung, the whole list)
+    assert BB.set_nms_fused_tail(False) is True
+    try:
+        sep = BB.nms(boxes, scores, max_ret=max_ret, return_keep=True)
+    finally:
+        assert BB.set_nms_fused_tail(True) is False
+    for x, y in zip(got, sep):
+        assert torch.equal(x, y)

@@ -3,7 +3,7 @@
 5 000): HIP-event time per call, median over groups, and a digest of the detections (two builds that print the same
 digest returned the same bits).  The A/B aid for everything behind the score scan.
 
-    python tools/exp_nms_single.py [--iters 20] [--groups 7] [--batch 64] [--tier F]      (F: bndbox.set_nms_tier, 0 = off)
+    python tools/exp_nms_single.py [--iters 20] [--groups 7] [--batch 64] [--tier F] [--fused 0|1]      (F: bndbox.set_nms_tier, 0 = off)
 """
 import argparse
 import hashlib
@@ -23,10 +23,13 @@ def main():
     ap.add_argument('--groups', type=int, default=7)
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--tier', type=int, default=None)
+    ap.add_argument('--fused', type=int, default=None, help='bndbox.set_nms_fused_tail: 1 = pass 1 as one launch (default), 0 = separate kernels')
     args = ap.parse_args()
     _lib.load()
     if args.tier is not None:
         BB.set_nms_tier(args.tier)
+    if args.fused is not None:
+        BB.set_nms_fused_tail(bool(args.fused))
     dev = _lib.require_gpu()
     c = workloads.CONFIGS[5]
     anchors = A.generate_anchors(A.AnchorsConfig(), c['S'])
@@ -54,8 +57,8 @@ def main():
     times.sort()
     byts = args.batch * workloads.nms_bytes_per_image(N, c['C'])
     med = times[len(times) // 2]
-    print('%s tier %s: per call min %.1f median %.1f max %.1f us  -> %.3f of 8 TB/s   digest %s' % (
-        os.environ.get('ODBOX_LIBRARY', 'default').split('libodbox_')[-1], args.tier, times[0], med, times[-1], byts / med / 8e6, h.hexdigest()[:12]))
+    print('%s tier %s fused %s: per call min %.1f median %.1f max %.1f us  -> %.3f of 8 TB/s   digest %s' % (
+        os.environ.get('ODBOX_LIBRARY', 'default').split('libodbox_')[-1], args.tier, args.fused, times[0], med, times[-1], byts / med / 8e6, h.hexdigest()[:12]))
 
 
 if __name__ == '__main__':

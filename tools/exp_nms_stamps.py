@@ -23,9 +23,19 @@ for base, what in ((32, 'coop <=3 chunks'), (40, 'coop 4 chunks'), (48, 'coop >4
         NAMES[base + i] = '%s: %s' % (what, ph)
 
 
+# (the fused pass-1 block, tier_tail_kernel, uses slots 40 .. 49; the cooperative blocks do not run beside it)
+FUSED = {40: 'fused: count', 41: 'fused: keys loaded', 42: 'fused: tier selection', 43: 'fused: class histogram / starts / scatter',
+         44: 'fused: rank sort', 45: 'fused: box gather + publish', 46: 'fused: rounds (per wave)', 47: 'fused: final keys to LDS (+ slowest wave)',
+         48: 'fused: chunk sorts + merges', 49: 'fused: emit'}
+
+
 def main():
     lib = _lib.load()
     dev = _lib.require_gpu()
+    if os.environ.get('ODBOX_STAMPS_FUSED', '1') != '0':      # ODBOX_STAMPS_FUSED=0: the separate kernels
+        NAMES.update(FUSED)
+    else:
+        BB.set_nms_fused_tail(False)
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     c = workloads.CONFIGS[5]
     anchors = A.generate_anchors(A.AnchorsConfig(), c['S'])

@@ -9,6 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from object_detection_amd import anchors as A, bndbox as BB, workloads  # noqa: E402
 
 S, C = 512, 90
+if len(sys.argv) > 1:                       # 0: the separate pass-1 kernels, 1: the fused block (bndbox.set_nms_fused_tail)
+    BB.set_nms_fused_tail(bool(int(sys.argv[1])))
+    print('fused tail:', sys.argv[1])
 anchors = A.generate_anchors(A.AnchorsConfig(), S)
 N = anchors.shape[0]
 for B in (1, 2, 4, 8, 16, 32, 64):
