@@ -518,8 +518,8 @@ def main():
                                    'drop-in rate; `pipelined` is what a caller that keeps two batches in flight gets'
                                    % (N5, C5, B5, B5),
                        'global_batch': world * B5},
-            'roofline': hbm_roofline('whole decode+NMS call: score_scan (HBM-bound), then partition, NMS, final top-k '
-                                     '(latency-bound)', bytes5, ev5 / args.nms_steps, med5, 'score_scan_kernel', spr5,
+            'roofline': hbm_roofline('whole decode+NMS call: score_scan (HBM-bound), then tier_tail_kernel (per-image tier, '
+                                     'partition, NMS and top-k in one block; latency-bound) and the pass-2 launch', bytes5, ev5 / args.nms_steps, med5, 'score_scan_kernel', spr5,
                                      frac_scores_only=round(B5 * N5 * C5 * 4 / med5 / 1e9 / HBM_PEAK_GBS, 4)),
             'detections_per_image_mean': float((out['det'][1] > 0).sum().item()) / (world * B5),
             'detections_sha1': digest.hexdigest(),

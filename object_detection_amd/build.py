@@ -85,6 +85,23 @@ def check_m0(hipcc, hooks, verbose=False):
     return sets
 
 
+def check_tail_vgprs(limit=96):
+    """The fused pass-1 block of decode+NMS (tier_tail_kernel: 1 024 threads, four waves per SIMD) has to become resident
+    on a CU whose SIMDs already hold one or two waves of ANOTHER batch's score scan (56 VGPRs each), or two batches in
+    flight (bndbox.DecodeNmsPipeline) stop overlapping: 4 x 96 + 2 x 56 <= 512.  __launch_bounds__(TT_THREADS, 5) asks
+    for that; this reads what the compiler really allocated from the assembly check_m0 has just written (measured:
+    118 VGPRs -> two batches in flight 195 us per batch instead of 180)."""
+    asm = os.path.join(OBJ, 'odbox_infer.s')
+    for raw in open(asm):
+        l = raw.strip()
+        if l.startswith('.set') and 'tier_tail_kernel' in l and '.num_vgpr,' in l:
+            n = int(l.rsplit(',', 1)[1])
+            if n > limit:
+                raise RuntimeError('tier_tail_kernel takes %d VGPRs (limit %d): it no longer fits beside a score scan' % (n, limit))
+            return n
+    raise RuntimeError('%s: tier_tail_kernel not found -- the check is looking at the wrong file' % asm)
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
@@ -100,6 +117,7 @@ def build(force=False, verbose=False):
         subprocess.run(cmd, check=True)
         objs.append(obj)
     check_m0(hipcc, hooks, verbose)
+    check_tail_vgprs()
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
     if verbose:
         print(' '.join(cmd))

@@ -1596,7 +1596,7 @@ static_assert(PART_THREADS == FIN_THREADS && TT_THREADS >= PART_THREADS && TT_WP
 static_assert(tier_tail_lds(90) <= TAIL_LDS_FIT, "the fused pass-1 block does not fit beside a scan");
 static_assert((TIER_BUCKETS + 2) * sizeof(int) <= TT_REGION / 2, "tier histogram in the lower half of the region");
 
-__global__ __launch_bounds__(TT_THREADS) void tier_tail_kernel(
+__global__ __launch_bounds__(TT_THREADS, 5) void tier_tail_kernel(
     const float4 *__restrict__ anchors, const BoxSrc rb, int N, int C, int do_clip, float hi_x, float hi_y, NmsThr thr,
     int max_ret, const int *__restrict__ cand_count, uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out,
     uint32_t cand_stride, uint32_t pre_nms_topk, uint32_t tier_k, uint32_t tier_first, int *__restrict__ seg_start,

@@ -20,6 +20,8 @@ if os.environ.get('EXP_OLDLIB'):       # a library built from an older commit (b
 
 def main():
     dev = torch.device('cuda', 0)
+    if os.environ.get('EXP_FUSED') in ('0', '1'):           # bndbox.set_nms_fused_tail
+        BB.set_nms_fused_tail(os.environ['EXP_FUSED'] == '1')
     S, B, C = 512, 64, 90
     anchors = A.generate_anchors(A.AnchorsConfig(), S)
     N = anchors.shape[0]
