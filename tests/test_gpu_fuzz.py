@@ -156,6 +156,62 @@ def test_decode_nms_random_shapes(seed):
     np.testing.assert_allclose(b, ref[0], rtol=1e-5, atol=0)
 
 
+@pytest.mark.parametrize('seed', range(32))
+def test_fused_pass_one_block_random_shapes(seed):
+    """The fused pass-1 block of decode+NMS (tier_tail_kernel) on random batches made for it: candidate counts below,
+    around and far above the tier's rungs, classes from one to hundreds with skewed shares (segments from singletons
+    to whole tiers, cut by window boundaries anywhere), groups of identical boxes with adjacent scores (low survival
+    rates: second rung, pass 2), exact score ties at the tier's edge, per-class caps from 1 up.  Against the C oracle
+    and, bit for bit, against the separate partition / NMS / final kernels."""
+    import torch
+    from object_detection_amd import bndbox as BB
+    rng = np.random.default_rng(77000 + seed)
+    B = int(rng.integers(1, 6))
+    N = int(rng.choice([300, 1000, 2500, 6000, 12000]))
+    C = int(rng.choice([1, 2, 5, 17, 90, 400]))
+    max_ret = int(rng.choice([1, 2, 7, 20, 50, 100, 113]))
+    S = 512.0
+    cx, cy = rng.uniform(0, S, N), rng.uniform(0, S, N)
+    w, h = rng.uniform(4, 60, N), rng.uniform(4, 60, N)
+    boxes = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).astype(np.float32)
+    boxes = np.broadcast_to(boxes, (B, N, 4)).copy()
+    sc = rng.uniform(0, 0.29, (B, N, C)).astype(np.float32)
+    quant = float(rng.choice([16, 256, 1 << 16]))
+    for b in range(B):
+        n_hot = int(min(N, rng.choice([0, 3, max_ret, 2 * max_ret + 3, 8 * max_ret, 16 * max_ret + 50, N])))
+        idx = rng.permutation(N)[:n_hot]
+        share = rng.dirichlet(np.full(C, float(rng.choice([0.05, 0.5, 5.0]))))          # skewed or even class shares
+        cls = rng.choice(C, n_hot, p=share)
+        val = 0.3 + 0.7 * rng.random(n_hot)
+        group = int(rng.choice([1, 1, 3, 12]))
+        if group > 1 and n_hot >= group:                    # groups of identical boxes, one class, adjacent scores
+            lead = idx[::group]
+            for j in range(1, group):
+                member = idx[j::group]
+                m = len(member)
+                boxes[b, member] = boxes[b, lead[:m]]
+                cls[j::group] = cls[::group][:m]
+                val[j::group] = val[::group][:m] - j * 2.0 ** -13
+        val = np.floor(val * quant) / quant + 1 / (2 * quant)
+        sc[b, idx, cls] = val.astype(np.float32)
+    thr_i = float(rng.choice([0.3, 0.45, 0.7]))
+    got = BB.nms(boxes, sc, iou_threshold=thr_i, max_ret=max_ret, return_keep=True)
+    ref = c_oracle.decode_nms(None, boxes, sc, (S, S), do_clip=False, iou_threshold=thr_i, max_ret=max_ret, threads=4)
+    b_, s_, l_, k_, n_ = (t.cpu().numpy() for t in got)
+    np.testing.assert_array_equal(n_, ref[4])
+    np.testing.assert_array_equal(k_, ref[3])
+    np.testing.assert_array_equal(l_, ref[2])
+    np.testing.assert_array_equal(s_, ref[1])
+    np.testing.assert_array_equal(b_, ref[0])               # decoded boxes handed over: copied, not recomputed
+    assert BB.set_nms_fused_tail(False) is True
+    try:
+        sep = BB.nms(boxes, sc, iou_threshold=thr_i, max_ret=max_ret, return_keep=True)
+    finally:
+        assert BB.set_nms_fused_tail(True) is False
+    for x, y in zip(got, sep):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize('seed', range(64))
 def test_sweep_random_shapes_and_placements(seed):
     """The lockstep sweep (ODBOX_POLICY_STREAM; wide label rows, short GT lists, labels on a 16-byte boundary): random
