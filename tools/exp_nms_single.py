@@ -23,6 +23,7 @@ def main():
     ap.add_argument('--groups', type=int, default=7)
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--tier', type=int, default=None)
+    ap.add_argument('--distinct', type=int, default=8, help='distinct synthetic images in the batch (bench.py: the whole batch)')
     ap.add_argument('--fused', type=int, default=None, help='bndbox.set_nms_fused_tail: 1 = pass 1 as one launch (default), 0 = separate kernels')
     args = ap.parse_args()
     _lib.load()
@@ -34,7 +35,7 @@ def main():
     c = workloads.CONFIGS[5]
     anchors = A.generate_anchors(A.AnchorsConfig(), c['S'])
     N = anchors.shape[0]
-    reg, sc = workloads.nms_inputs(N, C=c['C'], batch=args.batch, p3p4_anchors=9 * (64 * 64 + 32 * 32))
+    reg, sc = workloads.nms_inputs(N, C=c['C'], batch=args.batch, p3p4_anchors=9 * (64 * 64 + 32 * 32), distinct=args.distinct)
     reg, sc = torch.as_tensor(reg).to(dev), torch.as_tensor(sc).to(dev)
 
     def call():
@@ -54,6 +55,10 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         times.append(e0.elapsed_time(e1) * 1e3 / args.iters)
+    lib = _lib.load()
+    ws = _lib.workspace('decode_nms', dev, lib.odbox_decode_nms_workspace(args.batch, N, c['C'], 100, 5000))
+    state = ws[256 + 2 * args.batch * 64 * 4:][:4 * args.batch].view(torch.int32).cpu().tolist()
+    print('images by ladder rung (0 = pass 2; meaningful with the fused block only):', {k: state.count(k) for k in sorted(set(state))})
     times.sort()
     byts = args.batch * workloads.nms_bytes_per_image(N, c['C'])
     med = times[len(times) // 2]
