@@ -29,7 +29,7 @@ extern "C" {
 /* 200: the signatures of odbox_match_encode (trailing out_gt_best) and odbox_gt_prepare_xywh / _poly (`rows`) changed
  * against 100, and the first 256 bytes of the decode+NMS workspace became the library's epoch / ready line.  A caller
  * built against another header must not call in: compare odbox_version() with ODBOX_VERSION first. */
-#define ODBOX_VERSION 200            /* 0.2.0 */
+#define ODBOX_VERSION 201            /* 0.2.1: 200 + odbox_set_nms_fused_tail (no signature of 200 changed) */
 #define ODBOX_EINVAL (-1)            /* bad argument (shape, NULL, limit exceeded) */
 #define ODBOX_EHIP   (-2)            /* a HIP runtime call failed */
 #define ODBOX_ENOSPC (-3)            /* workspace too small */

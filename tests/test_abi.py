@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.odbox_version() == 200
+    assert lib.odbox_version() == 201
     assert isinstance(lib.odbox_last_error(), bytes)
 
 
