@@ -114,23 +114,33 @@ class Metric:
     def confusion_matrix(self):
         return self.cm.astype(int)
 
-    def per_entry_stats(self):
-        """calculate_metrics.py:214-236; returns the rows it prints."""
-        orig_cm = self.confusion_matrix()
-        cm = orig_cm[:-1, :-1]
-        sum_pred = np.sum(cm, axis=0)
-        sum_true = np.sum(cm, axis=1)
-        rows = []
-        for cid, cname in zip(self.cat_ids[:-1], self.cat_names[:-1]):
-            tp = cm[cid][cid]
-            fp = sum_pred[cid] - tp
-            fn = sum_true[cid] - tp
-            rc = tp / (tp + fn + 1e-10) * 100
-            pr = tp / (tp + fp + 1e-10) * 100
-            f1 = 2 * pr * rc / (pr + rc + 1e-10)
-            undetected = orig_cm[cid][self.none_id] / (np.sum(orig_cm[cid, :]) + 1e-10) * 100
-            unlabeled = orig_cm[self.none_id][cid] / (np.sum(orig_cm[:, cid]) + 1e-10) * 100
-            print('{: >20s}/{:2d}: f1: {:.1f}, precision: {:.1f}, recall: {:.1f}, tp: {:4d}, fp: {:4d}, fn: {:4d}, undetected: {:.1f}, unlabelled: {:.1f}'.format(
-                cname, cid, f1, pr, rc, tp, fp, fn, undetected, unlabeled))
-            rows.append((f1, pr, rc, int(tp), int(fp), int(fn), undetected, unlabeled))
+    def per_entry_stats(self, report=True):
+        """calculate_metrics.py:214-236, all classes at once: one row (f1, precision, recall, tp, fp, fn, undetected,
+        unlabeled) per real class, in percent where the reference prints percent, with the reference's `+ 1e-10`
+        guards and its order of operations (float64, so the rows equal the per-class loop bit for bit).  The report
+        (one line per class) goes through `format_stats`; report=False only returns the rows."""
+        full = self.confusion_matrix()
+        k = self.none_id                                    # the trailing 'none' class is not a row
+        inner = full[:k, :k]
+        tp = np.diagonal(inner)
+        fp = inner.sum(axis=0) - tp
+        fn = inner.sum(axis=1) - tp
+        recall = tp / (tp + fn + 1e-10) * 100
+        precision = tp / (tp + fp + 1e-10) * 100
+        f1 = 2 * precision * recall / (precision + recall + 1e-10)
+        undetected = full[:k, k] / (full[:k, :].sum(axis=1) + 1e-10) * 100
+        unlabeled = full[k, :k] / (full[:, :k].sum(axis=0) + 1e-10) * 100
+        rows = [(f1[c], precision[c], recall[c], int(tp[c]), int(fp[c]), int(fn[c]), undetected[c], unlabeled[c])
+                for c in range(k)]
+        if report:
+            print(format_stats(self.cat_names[:k], rows))
         return rows
+
+
+def format_stats(names, rows):
+    """The per-class report of `Metric.per_entry_stats` as text: the reference's eight figures per class."""
+    head = ('class', 'f1', 'precision', 'recall', 'tp', 'fp', 'fn', 'undetected', 'unlabelled')
+    lines = ['%20s %6s %9s %6s %5s %5s %5s %10s %10s' % head]
+    for cid, (name, r) in enumerate(zip(names, rows)):
+        lines.append('%17s/%2d %6.1f %9.1f %6.1f %5d %5d %5d %10.1f %10.1f' % ((name, cid) + tuple(r)))
+    return '\n'.join(lines)
