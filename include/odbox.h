@@ -246,10 +246,12 @@ int odbox_scale_boxes(const float *boxes /*[n,4]*/, size_t n, float fx, float fy
  * kept boxes above a score are decided by the candidates above that score alone.  Pass 1 therefore runs partition /
  * NMS / top-k on every image's best factor * max_ret candidates (ties at the edge included); an image whose tier
  * keeps at least max_ret boxes is finished, the others are done again on their whole list by pass 2 (one more
- * launch, in which blocks of finished images leave at once).  On BASELINE configs[4] (4 500 candidates per image,
- * max_ret 100) every image finishes in pass 1 and a call takes 209 us instead of 228; a batch in which EVERY image
- * falls through to pass 2 takes 267 us.  factor: default 8; 0 turns the tier off (a caller whose images keep fewer
- * than one candidate in eight).  Process-wide; returns the previous factor, or ODBOX_EINVAL. */
+ * launch, in which blocks of finished images leave at once).  factor is the LARGEST tier pass 1 tries: the fused pass-1
+ * block (odbox_set_nms_fused_tail) starts on the best factor / 4 * max_ret candidates and grows the tier only when
+ * those keep too few.  On BASELINE configs[4] (4 500 candidates per image, max_ret 100) every image finishes in pass 1
+ * and a call takes 197-201 us instead of 228 without a tier; a batch in which EVERY image falls through to pass 2 takes
+ * 270-280 us.  factor: default 8; 0 turns the tier off (a caller whose images keep fewer than one candidate in eight).
+ * Process-wide; returns the previous factor, or ODBOX_EINVAL. */
 int odbox_set_nms_tier(int factor);
 
 /* Pass 1 of odbox_decode_nms as ONE launch (no counterpart in the reference; the same bits either way).  on = 1
