@@ -1018,6 +1018,18 @@ constexpr int NMS_WAVES = 8;
 #endif
 constexpr int NMS_REG_KEPT = 128;
 
+// A kept key into the image's final list.  through (pass 2 only): as an agent-scope store, which is written through
+// the XCD's L2 -- pass 2's final top-k of an image runs in whichever block finishes its last segment, on any XCD, and
+// with the keys already at the coherence point that block's hand-off is "wait for my stores, add to the image's
+// counter" instead of a release fence, i.e. an L2 write-back, per block (all images in pass 2: 272 -> 26x us a call).
+__device__ __forceinline__ void put_key(uint64_t *slot, uint64_t key, bool through)
+{
+    if (through)
+        __hip_atomic_store(slot, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *slot = key;
+}
+
 __device__ __forceinline__ int nms_wave_segment(
     unsigned char *s_raw, uint32_t block, const float4 *__restrict__ anchors, const BoxSrc rb, int N,
     int C, int do_clip, float hi_x, float hi_y, NmsThr thr, int max_ret, const uint64_t *__restrict__ cand_keys,
@@ -1142,11 +1154,11 @@ __device__ __forceinline__ int nms_wave_segment(
         const unsigned long long below = (1ull << lane) - 1ull;
         if ((kmask0 >> lane) & 1ull) {
             const uint32_t pos = (uint32_t)(base + __popcll(kmask0 & below));
-            if (pos < fin_stride) fin_keys[(size_t)b * fin_stride + pos] = cand_to_final(key0);
+            if (pos < fin_stride) put_key(fin_keys + (size_t)b * fin_stride + pos, cand_to_final(key0), done != nullptr);
         }
         if ((kmask1 >> lane) & 1ull) {
             const uint32_t pos = (uint32_t)(base + __popcll(kmask0) + __popcll(kmask1 & below));
-            if (pos < fin_stride) fin_keys[(size_t)b * fin_stride + pos] = cand_to_final(key1);
+            if (pos < fin_stride) put_key(fin_keys + (size_t)b * fin_stride + pos, cand_to_final(key1), done != nullptr);
         }
         return (int)b;
     }
@@ -1242,7 +1254,7 @@ __device__ __forceinline__ int nms_wave_segment(
     out_base = __shfl(out_base, 0);
     for (int k = (int)lane; k < kept; k += WAVE) {
         const uint32_t pos = (uint32_t)(out_base + k);
-        if (pos < fin_stride) fin_keys[(size_t)b * fin_stride + pos] = cand_to_final(s_key[k]);
+        if (pos < fin_stride) put_key(fin_keys + (size_t)b * fin_stride + pos, cand_to_final(s_key[k]), done != nullptr);
     }
     return (int)b;
 }
@@ -1377,7 +1389,7 @@ __device__ __forceinline__ void nms_coop_block(
         const int out_base = *s_base;
         for (int k = (int)tid; k < kept_total; k += NMS_WAVES * WAVE) {
             const uint32_t pos = (uint32_t)(out_base + k);
-            if (pos < fin_stride) fin_keys[(size_t)b * fin_stride + pos] = cand_to_final(s_kkey[k]);
+            if (pos < fin_stride) put_key(fin_keys + (size_t)b * fin_stride + pos, cand_to_final(s_kkey[k]), stay);
         }
         __syncthreads();
         item_done(b);
@@ -1567,9 +1579,9 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
 // sorted out as in finalize_image.
 // THE LADDER.  Any tier that keeps max_ret boxes gives the exact detections, and the block's cost grows with the
 // tier, so the first attempt takes a quarter of the largest tier (factor 8: the best 2 max_ret candidates).  If that
-// keeps too few, the second attempt's size comes from the first one's survival rate (1.5 max_ret / rate, at least
-// twice the first, at most the largest tier); an image whose rate says that even the largest tier will not hold
-// max_ret survivors, whose tier does not fit (more than TT_CAP keys with the ties at its edge) or whose list the
+// keeps too few, ONE more attempt follows, sized from the first one's survival rate (twice 1.5 max_ret / rate, at
+// most the largest tier); an image whose rate says that even the largest tier will not hold max_ret survivors, whose
+// second attempt fails too, whose tier does not fit (more than TT_CAP keys with the ties at its edge) or whose list the
 // pre-NMS top-k cuts is partitioned for pass 2 right here, like the pass-1 final kernel does it.  state[b] records
 // which attempt finished the image (0: pass 2).  On the configs[4] share: 18.7 us against 4 + 12 + 7 us and two
 // boundaries, one call 207 -> 197 us on one box (tools/exp_nms_single.py --fused 0 / 1).
@@ -1622,9 +1634,9 @@ __global__ __launch_bounds__(TT_THREADS, 5) void tier_tail_kernel(
     // block-uniform: lists the pre-NMS top-k cuts, or longer than the block's registers, are pass 2's whole
     bool again = (pre_nms_topk != 0u && M_all > pre_nms_topk) || M_all > (uint32_t)(TT_REG * TT_THREADS);
     // The tier ladder: the first attempt takes a SMALL tier (tier_first candidates: a quarter of the largest); if it keeps
-    // max_ret boxes they are the image's detections (any tier that does is exact).  If not, the next attempt's size is
-    // read off the first one's survival rate -- 1.5 max_ret / (kept / tier) -- and an image whose rate says that even the
-    // largest tier will not do goes to pass 2 at once.  Every test below is block-uniform.
+    // max_ret boxes they are the image's detections (any tier that does is exact).  If not, the second and last attempt's
+    // size is read off the first one's survival rate, and an image whose rate says that even the largest tier will not
+    // do goes to pass 2 at once.  Every test below is block-uniform.
     uint32_t tk = min(tier_first, tier_k);
     int rung = 1;                                             // state[b]: 0 = left to pass 2, else the attempt that finished the image
     while (!again) {
@@ -1874,11 +1886,13 @@ __global__ __launch_bounds__(TT_THREADS, 5) void tier_tail_kernel(
             ODBOX_LAP(stp, 49, tid == 0);                     // winners decoded and stored
             break;
         }
-        // not enough survivors: the tier that can be expected to hold max_ret of them, with half as many again to spare
+        // not enough survivors.  ONE more attempt, if the survival rate says that a tier within the largest one can
+        // hold max_ret of them (with half as many again to spare); it takes twice that estimate -- the rate falls with
+        // depth, and a third attempt would cost more than the chip-wide pass 2 (tools/exp_nms_overlap.py)
         const uint64_t want = ((uint64_t)max_ret * M * 3u) / (2u * max(total_kept, 1u)) + 1u;
-        again = tk >= tier_k || want > (uint64_t)tier_k;
+        again = rung >= 2 || tk >= tier_k || want > (uint64_t)tier_k;
         if (again) break;
-        tk = min(tier_k, max((uint32_t)want, 2u * tk));
+        tk = (uint32_t)min((uint64_t)tier_k, max(2u * want, (uint64_t)2u * tk));
         ++rung;
         __syncthreads();                                      // the LDS starts over
     }
@@ -1903,9 +1917,9 @@ struct FinalArgs {                     // what finalize_image needs beyond the N
 
 // fuse (pass 2 only): the block that finishes the LAST of an image's C segments also runs the image's final top-k, so
 // pass 2 is this one launch.  Every block tells how many segments of an image it has finished with one atomic add on
-// the image's counter (fin_count line, word 1; zeroed when pass 2 of the image was started), behind an agent-scope
-// release of the kept keys its waves stored; the block whose add completes the count acquires and reads them.  No
-// block ever waits for another.  Pass 1 and the single plain pass keep their own final kernel and pay none of this.
+// the image's counter (fin_count line, word 1; zeroed when pass 2 of the image was started) once the kept keys its
+// waves stored -- agent-scope stores, written through the L2 (put_key) -- have been acknowledged; the block whose add
+// completes the count acquires and reads them.  No block ever waits for another.  Pass 1 and the single plain pass keep their own final kernel and pay none of this.
 template <bool FUSE>
 __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
     const float4 *__restrict__ anchors, const BoxSrc rb, int N, int C, int do_clip,
@@ -1941,8 +1955,8 @@ __global__ __launch_bounds__(NMS_WAVES *WAVE) void nms_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's kept keys have left it
             __syncthreads();
             if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // (no release fence: the kept keys went out as agent-scope stores, see put_key, and every wave has waited
+                // for its own before the barrier above)
                 const int before = atomicAdd(fin_count + b * CNT_STRIDE + 1, count);
                 const bool last = before + count >= C;
                 if (last) {
