@@ -1638,6 +1638,10 @@ __global__ __launch_bounds__(TT_THREADS, 5) void tier_tail_kernel(
     // size is read off the first one's survival rate, and an image whose rate says that even the largest tier will not
     // do goes to pass 2 at once.  Every test below is block-uniform.
     uint32_t tk = min(tier_first, tier_k);
+    // a list within the largest tier: whole at once, final whatever it keeps -- a bounded cost instead of a bet on the
+    // first rung (800-candidate lists, tools/exp_nms_overlap.py: piles that collapse 196 us a call against 204 through
+    // the rung, piles that half overlap 221 against 236; only lists that barely overlap would have won the bet)
+    if (M_all <= tier_k) tk = tier_k;
     int rung = 1;                                             // state[b]: 0 = left to pass 2, else the attempt that finished the image
     while (!again) {
         uint32_t M = M_all;
@@ -1890,9 +1894,10 @@ __global__ __launch_bounds__(TT_THREADS, 5) void tier_tail_kernel(
         // hold max_ret of them (with half as many again to spare); it takes twice that estimate -- the rate falls with
         // depth, and a third attempt would cost more than the chip-wide pass 2 (tools/exp_nms_overlap.py)
         const uint64_t want = ((uint64_t)max_ret * M * 3u) / (2u * max(total_kept, 1u)) + 1u;
-        again = rung >= 2 || tk >= tier_k || want > (uint64_t)tier_k;
+        const bool fits_whole = M_all <= tier_k;              // the largest tier is the whole list: final whatever it keeps
+        again = rung >= 2 || tk >= tier_k || (want > (uint64_t)tier_k && !fits_whole);
         if (again) break;
-        tk = (uint32_t)min((uint64_t)tier_k, max(2u * want, (uint64_t)2u * tk));
+        tk = fits_whole ? tier_k : (uint32_t)min((uint64_t)tier_k, max(2u * want, (uint64_t)2u * tk));
         ++rung;
         __syncthreads();                                      // the LDS starts over
     }
