@@ -1882,11 +1882,41 @@ __global__ __launch_bounds__(TT_THREADS, 5) void tier_tail_kernel(
         __syncthreads();
         ODBOX_LAP(stp, 47, tid == 0);                         // final keys in LDS (waits for the slowest wave)
         if (whole || total_kept >= (uint32_t)max_ret) {
-            best128_of_chunks<TT_WAVES>(s_keys, nchunks, tid);
+            uint64_t *s_best = s_keys;                        // the sorted best FIN_CHUNK keys
+            if (nchunks <= 4u && TT_THREADS == 1024) {
+                // at most 512 kept keys (the usual first rung, every short list): a key's place is the number of smaller
+                // keys -- the block's threads share the keys out, 1024 / K threads per key, each counts its part of the
+                // K keys (broadcast reads) and adds it up in LDS.  The 128-key sorting network costs 2.1 us even for an
+                // empty list (28 shuffle stages), this 0.5; from 1 024 keys on the network wins.
+                const uint32_t K = nchunks <= 1u ? FIN_CHUNK : nchunks == 2u ? 2u * FIN_CHUNK : 4u * FIN_CHUNK;
+                const uint32_t per = K * K / (uint32_t)TT_THREADS;                   // keys each thread looks at: 16 / 64 / 256
+                int *s_rank = reinterpret_cast<int *>(s_keys + K);                   // [K], then the sorted best
+                s_best = s_keys + K + K / 2u;
+                for (uint32_t p = nchunks * FIN_CHUNK + tid; p < K; p += TT_THREADS) s_keys[p] = ~0ull;     // (three chunks: pad to four)
+                if (tid < K) s_rank[tid] = 0;
+                __syncthreads();
+                const uint32_t t = tid & (K - 1u), part = tid / K;
+                const uint64_t mine = s_keys[t];
+                const uint64_t *from = s_keys + part * per;
+                uint32_t r = 0;
+                for (uint32_t j = 0; j < per; j += 8u) {
+                    uint64_t kk[8];
+#pragma unroll
+                    for (uint32_t u = 0; u < 8u; ++u) kk[u] = from[j + u];
+#pragma unroll
+                    for (uint32_t u = 0; u < 8u; ++u) r += kk[u] < mine ? 1u : 0u;
+                }
+                if (r != 0u) atomicAdd(&s_rank[t], (int)r);
+                __syncthreads();
+                if (tid < K && (uint32_t)s_rank[tid] < FIN_CHUNK) s_best[s_rank[tid]] = mine;      // (the ~0 padding shares its places: never read)
+                __syncthreads();
+            } else {
+                best128_of_chunks<TT_WAVES>(s_keys, nchunks, tid);
+            }
             ODBOX_LAP(stp, 48, tid == 0);                     // chunk sorts and merges
             const uint32_t keep = min(total_kept, (uint32_t)max_ret);
             if (out_count && tid == 0) out_count[b] = (int32_t)keep;
-            emit_detections(s_keys, keep, b, anchors, rb, N, do_clip, hi_x, hi_y, max_ret, out_boxes, out_scores, out_labels, out_keep);
+            emit_detections(s_best, keep, b, anchors, rb, N, do_clip, hi_x, hi_y, max_ret, out_boxes, out_scores, out_labels, out_keep);
             ODBOX_LAP(stp, 49, tid == 0);                     // winners decoded and stored
             break;
         }

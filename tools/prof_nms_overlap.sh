@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_overlap
 rm -rf $OUT; mkdir -p $OUT
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/exp_nms_overlap.py > $OUT/log.txt 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/exp_nms_overlap.py $OVERLAP_ARGS > $OUT/log.txt 2>&1 || exit 1
 python3 - <<'PY'
 import csv,glob,os
 root=os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/prof_overlap'
