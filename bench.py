@@ -132,15 +132,15 @@ def timed(fn, steps, warmup, world):
     and the garbage collector stays out of it."""
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for i in range(warmup):
-        fn(i)
-    e1.record()
-    torch.cuda.synchronize()
-    e0.elapsed_time(e1)
-    gc.collect()
-    gc.disable()
+    gc.collect()              # before the warm-up, not between it and the timed region: a collection idles the GPU for
+    gc.disable()              # tens of ms, and the first of only K = 20 timed steps then run while its clocks ramp up
     try:
+        e0.record()
+        for i in range(warmup):
+            fn(i)
+        e1.record()
+        torch.cuda.synchronize()
+        e0.elapsed_time(e1)
         barrier(world)
         t0 = time.perf_counter()
         e0.record()
