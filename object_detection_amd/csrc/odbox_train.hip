@@ -180,7 +180,7 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
     __shared__ unsigned long long s_gseed[GTBEST ? ME_GCHUNK : 1];
     __shared__ float4 s_gt[ME_GCHUNK];
     __shared__ float2 s_ga[ME_GCHUNK];          // (area, 1.0 if padded row else 0.0)
-    __shared__ uint16_t s_list[TILE / WAVE][ME_GCHUNK];      // per wave: GT rows it must evaluate
+    __shared__ uint16_t s_list[TILE / WAVE][ME_GCHUNK + FAST_ROWS];      // per wave: GT rows it must evaluate (+ slack for the read-ahead)
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const uint32_t n = n0 + tid;
@@ -275,13 +275,14 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
         // ---- the usual case, division-free: every area in play is finite and >= 0, so every IoU is a number >= +0
         // (an intersection is at most the smaller area, hence finite; a sum of areas that overflows gives 0) --------
         // The correctly rounded division is 13 of the ~29 issue cycles of a pair, and all the argmax needs
-        // from it is "is this row's quotient greater than the best so far".  q = i * rcp(u) is within
-        // 2^-22 of the true ratio (v_rcp_f32: 1 ulp), the rounded quotients within 2^-24: two rows whose q
-        // differ by more than 2^-19 relative compare the same way as their exact quotients, and only a
-        // row inside that band of the running best (a tie, or next to one: practically never) takes the
-        // exact IEEE divisions, of both.  i == 0 is the exact quotient +0 and never beats a best >= 0
-        // (strict >, first maximum wins).  The best row's exact IoU is computed once, after the loop.
-        // Same decisions as the exact loop below, row by row, hence the same argmax and the same value
+        // from it is "which row has the greatest quotient".  q = i * rcp(u) is within 2^-22 of the true ratio
+        // (v_rcp_f32: 1 ulp), the rounded quotients within 2^-24: two rows whose q differ by more than 2^-19
+        // relative compare the same way as their exact quotients.  So the loop keeps the TWO largest q of the
+        // chunk (and the exact best of the chunks before it) -- a compare, a select, one v_med3 and one v_max per row,
+        // no band arithmetic -- and only when the runner-up ends inside that band of the winner (a tie, or next to
+        // one: practically never) is the chunk's list walked again with the exact IEEE divisions.  i == 0 is the exact
+        // quotient +0 and 0 is never inside the band of 0 (strict >, first maximum wins).  The best row's exact IoU is
+        // computed once, after the loop.  Same argmax and the same value as the exact loop below
         // (tests/test_gpu_match.py::test_ties_and_near_ties_in_the_division_free_matcher).
         auto post_chunk = [&] {
             if (!GTBEST) return;
@@ -293,55 +294,46 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
             }
         };
         if (can_skip_zero && odd_rows == 0ull && nlist != 0u) {
-            constexpr float BAND_HI = 1.0f + 0x1p-19f, BAND_LO = 1.0f - 0x1p-19f;
+            constexpr float BAND_HI = 1.0f + 0x1p-19f;
             auto exact_iou = [&](int row) {
                 const float4 bb = row >= g0 ? s_gt[row - g0] : gtb[row];
                 return pair_iou(a, a_area, bb, (bb.w - bb.y) * (bb.z - bb.x));
             };
-            // best so far as an approximate quotient: -inf = none yet, 0 = an exact zero
-            float qb = best_iou;
-            // R rows at a time: their LDS reads and quotients are independent, only the short
-            // compare / select chain is serial; one ballot per group asks whether any lane met a band row
-            auto rows = [&](uint32_t k, auto rc) {
+            // best so far as an approximate quotient (-inf = none yet, 0 = an exact zero) and the runner-up
+            float qb = best_iou, q2 = -INFINITY;
+            const int best_in = best;
+            const float best_iou_in = best_iou;
+            // R rows at a time.  The wave runs beside five or six others and its own chain of LDS round trips (list entry
+            // -> box -> arithmetic, row after row as hipcc schedules it when left alone) is what bounds the loop, not the
+            // VALU count: so the R boxes and areas are read back to back behind a scheduling barrier -- one round trip
+            // per step -- and the step's list entries arrive with the step before (`g`, read ahead by the caller).
+            auto rows = [&](const int *g, auto rc) {
                 constexpr int R = decltype(rc)::value;
-                int g[R];
                 float ia[R], ua[R], q[R];
+                float4 gb[R];
+                float g_area[R];
 #pragma unroll
-                for (int r = 0; r < R; ++r) g[r] = s_list[wave][k + r];
+                for (int r = 0; r < R; ++r) {
+                    gb[r] = s_gt[g[r]];
+                    g_area[r] = s_ga[g[r]].x;
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 // (two rows per v_pk_add_f32 / v_pk_mul_f32 were tried for the subtractions, products and sums: same-box
                 // A/B on configs[3] 352-358 us packed against 340-346 us plain -- the register pairing costs more moves
                 // than the packing saves)
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const float4 gb = s_gt[g[r]];
-                    const float g_area = s_ga[g[r]].x;
-                    const float ix0 = vmax(a.x, gb.x), ix1 = vmin(a.z, gb.z);
-                    const float iy0 = vmax(a.y, gb.y), iy1 = vmin(a.w, gb.w);
+                    const float ix0 = vmax(a.x, gb[r].x), ix1 = vmin(a.z, gb[r].z);
+                    const float iy0 = vmax(a.y, gb[r].y), iy1 = vmin(a.w, gb[r].w);
                     ia[r] = vmax(ix1 - ix0, 0.0f) * vmax(iy1 - iy0, 0.0f);
-                    ua[r] = ((a_area + g_area) - ia[r]) + 1e-8f;                         // bndbox.py:289, > 0 here
+                    ua[r] = ((a_area + g_area[r]) - ia[r]) + 1e-8f;                      // bndbox.py:289, > 0 here
                     q[r] = ia[r] * __builtin_amdgcn_rcpf(ua[r]);
                 }
-                const float qb0 = qb;
-                const int best0 = best;
-                bool any_band = false;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const bool take = q[r] * BAND_LO > qb;
-                    // (strict: q == 0 against a best of exactly 0 is a plain tie, not a band case -- and the band is
-                    // eight times wider than the error of q, so its edge can stay out)
-                    any_band = any_band || (!take && q[r] * BAND_HI > qb);
-                    qb = take ? q[r] : qb;
-                    best = take ? g0 + g[r] : best;
-                }
-                if (__ballot(any_band) != 0ull) {                  // wave-uniform, practically never: these rows again, exactly
-                    float vb = qb0 == -INFINITY ? qb0 : exact_iou(best0);
-                    best = best0;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const float v = ia[r] / ua[r];
-                        if (v > vb) { vb = v; best = g0 + g[r]; }
-                    }
-                    qb = vb;
+                    best = q[r] > qb ? g0 + g[r] : best;                   // strict: the first of equal quotients stays
+                    q2 = __builtin_amdgcn_fmed3f(q[r], qb, q2);            // q2 <= qb: the median is the new runner-up
+                    qb = vmax(qb, q[r]);
                 }
                 if (GTBEST) {
                     // per-GT best anchor: can any lane reach the row's best so far?  The key's upper word is the
@@ -380,9 +372,38 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
                 }
             };
             uint32_t k = 0;
-            for (; k + FAST_ROWS <= nlist; k += FAST_ROWS) rows(k, std::integral_constant<int, FAST_ROWS>{});
-            for (; k < nlist; ++k) rows(k, std::integral_constant<int, 1>{});
-            best_iou = exact_iou(best);
+#ifdef ODBOX_EXP_ROWS_SHIFT
+            nlist >>= ODBOX_EXP_ROWS_SHIFT;
+#endif
+            if (nlist >= (uint32_t)FAST_ROWS) {
+                int gn[FAST_ROWS];
+#pragma unroll
+                for (int r = 0; r < FAST_ROWS; ++r) gn[r] = s_list[wave][r];
+                for (; k + FAST_ROWS <= nlist; k += FAST_ROWS) {
+                    int g[FAST_ROWS];
+#pragma unroll
+                    for (int r = 0; r < FAST_ROWS; ++r) g[r] = gn[r];
+                    // the next step's entries (the list has FAST_ROWS slots of slack behind its last row: read, never used)
+#pragma unroll
+                    for (int r = 0; r < FAST_ROWS; ++r) gn[r] = s_list[wave][k + FAST_ROWS + r];
+                    rows(g, std::integral_constant<int, FAST_ROWS>{});
+                }
+            }
+            for (; k < nlist; ++k) {
+                const int g1 = s_list[wave][k];
+                rows(&g1, std::integral_constant<int, 1>{});
+            }
+            if (__ballot(q2 * BAND_HI > qb) != 0ull) {         // wave-uniform, practically never: this chunk again, exactly
+                best = best_in;
+                best_iou = best_iou_in;
+                for (k = 0; k < nlist; ++k) {
+                    const int g = s_list[wave][k];
+                    const float v = pair_iou(a, a_area, s_gt[g], s_ga[g].x);
+                    if (v > best_iou) { best_iou = v; best = g0 + g; }
+                }
+            } else {
+                best_iou = exact_iou(best);
+            }
             post_chunk();
             continue;
         }
@@ -452,17 +473,24 @@ __global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE_ENC) void match_e
     // ... and both orders run back to front: the coarse pyramid levels at the end of the anchor array
     // have the longest work lists (every GT row reaches into their tiles), so they go first and the
     // launch ends on cheap tiles (config 4: 413 -> 400 us, configs 1 / 3: -1.5 % / -1 %)
-    const uint32_t blk = gridDim.x - 1u - (remap && !GTBEST ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x);
+    // remap == 2 (many GT rows, small output): tile-major like GTBEST below -- the coarse tiles of ALL images first.  Their
+    // waves walk every GT row (ten times the average list) and live ten times as long; image-major order starts the
+    // last image's coarse tiles at the very end of the launch and the chip then waits for a few waves that run alone
+    // (configs[3]: the launch took the same 340 us with 11 % fewer VALU instructions and with a third of the LDS
+    // round trips -- only the average occupancy fell; tools/exp_cfg4_per_launch.py, profiles/README.md)
+    const bool tile_major = GTBEST || remap == 2u;
+    const uint32_t blk = gridDim.x - 1u - (remap == 1u && !GTBEST ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x);
     // GTBEST: tile-major order (all images' last tile, then all images' tile before it, ...), so that the tiles of one
     // image run one after the other rather than all at once: a tile then finds the per-GT keys its predecessors posted
     // and most of its (wave, row) pairs fail the "can I reach the best so far" test instead of reducing over the
     // wavefront (dense crowd with the output on: 700 us with all tiles of an image in flight together).  XCD = block
     // mod 8 = image mod 8: balanced, and an image's GT rows and keys stay in one L2.
     const uint32_t n_img = gridDim.x / tiles_per_image;
-    const uint32_t b = GTBEST ? blk % n_img : blk / tiles_per_image;
+    const uint32_t b = tile_major ? blk % n_img : blk / tiles_per_image;
     // (GTBEST: `remap` carries a multiplier coprime to tiles_per_image -- the tiles of an image in a scattered order: a
     // sweep through the anchor grid approaches every GT box step by step, and every step raises its best)
-    const uint32_t n0 = (GTBEST ? (uint32_t)(((uint64_t)(blk / n_img) * remap) % tiles_per_image) : blk - b * tiles_per_image) * TILE;
+    const uint32_t n0 = (GTBEST ? (uint32_t)(((uint64_t)(blk / n_img) * remap) % tiles_per_image)
+                                : tile_major ? blk / n_img : blk - b * tiles_per_image) * TILE;
     const uint32_t n = n0 + tid;
     const bool live = n < (uint32_t)N;
     const uint32_t tile_n = min((uint32_t)TILE, (uint32_t)N - n0);
@@ -1581,7 +1609,11 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
 #ifdef ODBOX_ENC_REMAP_FORCE
     const uint32_t remap = ODBOX_ENC_REMAP_FORCE;
 #else
-    const uint32_t remap = (!stream_out && label_bytes > 0 && label_bytes <= (384ull << 20) && G <= 64) ? 0u : 1u;
+    uint32_t remap = (!stream_out && label_bytes > 0 && label_bytes <= (384ull << 20) && G <= 64) ? 0u : 1u;
+    // the matcher is the cost, not the stores: long lists first, chip-wide (XCD = image mod 8 once there are 8 images;
+    // fewer would bring back the tile-mod-8 imbalance described above)
+    if (!stream_out && G > 64 && B >= 8) remap = 2u;
+    if (const char *e = train_tuning_env("ODBOX_ENC_REMAP")) remap = (uint32_t)atoi(e);
 #endif
     const int tile = stream_out ? ME_TILE_STREAM : ME_TILE_ENC;
     const uint64_t tiles = ((uint64_t)N + tile - 1) / tile;
