@@ -120,6 +120,14 @@ constexpr int ME_GCHUNK = ODBOX_ME_GCHUNK;      // GT rows staged in LDS at a ti
 #define ODBOX_FAST_ROWS 4                  // GT rows per step of the division-free matcher loop
 #endif
 constexpr int FAST_ROWS = ODBOX_FAST_ROWS;
+// work-list entries of match_tile: 16 bits hold every offset and cost one extraction per row; 32-bit entries cost none but
+// 4 KB more LDS per 256-anchor block (same-box A/B, configs[3]: 288-290 us against 300-303 us; the fused loss forward
+// 41.2 against 43.0 us)
+#ifdef ODBOX_LIST32
+typedef uint32_t ListEntry;
+#else
+typedef uint16_t ListEntry;
+#endif
 
 // Phases 1 and 2 of the matcher for the calling thread's anchor n0 + threadIdx.x of image b:
 // anchors.py:215-274 (argmax IoU, thresholds), :178-184 (out-of-image), :187-194 (label).
@@ -178,9 +186,15 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
 {
     __shared__ unsigned long long s_gbest[GTBEST ? ME_GCHUNK : 1];
     __shared__ unsigned long long s_gseed[GTBEST ? ME_GCHUNK : 1];
-    __shared__ float4 s_gt[ME_GCHUNK];
-    __shared__ float2 s_ga[ME_GCHUNK];          // (area, 1.0 if padded row else 0.0)
-    __shared__ uint16_t s_list[TILE / WAVE][ME_GCHUNK + FAST_ROWS];      // per wave: GT rows it must evaluate (+ slack for the read-ahead)
+    // one staged GT row: box, area, 1.0 if padded row else 0.0 -- 32 bytes, so that one LDS address serves the box
+    // (ds_read_b128) and the area (ds_read_b32 at +16)
+    struct __align__(16) GtRow { float4 box; float area; float pad; float spare[2]; };
+    __shared__ GtRow s_row[ME_GCHUNK];
+    // per wave: the GT rows it must evaluate, as BYTE OFFSETS into s_row (row * 32: the matcher loop spends no VALU
+    // instruction on addresses, and the best row is carried as its offset), + slack for the read-ahead
+    __shared__ __align__(16) ListEntry s_list[TILE / WAVE][ME_GCHUNK + FAST_ROWS];
+    static_assert(sizeof(GtRow) == 32 && (size_t)ME_GCHUNK * sizeof(GtRow) <= (size_t)(ListEntry)~(ListEntry)0 + 1, "list entries are byte offsets of 32-byte rows");
+    auto row_at = [&](uint32_t off) -> const GtRow & { return *reinterpret_cast<const GtRow *>(reinterpret_cast<const char *>(s_row) + off); };
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const uint32_t n = n0 + tid;
@@ -221,8 +235,9 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
             float4 gb = gtb[g0 + g];
             float area = (gb.w - gb.y) * (gb.z - gb.x);                  // bndbox.py:286
             float gmax = vmax(vmax(gb.x, gb.y), vmax(gb.z, gb.w));    // bndbox.py:295
-            s_gt[g] = gb;
-            s_ga[g] = make_float2(area, gmax < 0.0f ? 1.0f : 0.0f);
+            s_row[g].box = gb;
+            s_row[g].area = area;
+            s_row[g].pad = gmax < 0.0f ? 1.0f : 0.0f;
             if (GTBEST) {
                 // device scope: a plain load would be served by this XCD's L2, which never sees the other XCDs' atomics
                 const unsigned long long seed = __hip_atomic_load(&gbest_keys[(size_t)b * G + g0 + g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -244,8 +259,8 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
             const int g = gs + (int)lane;
             bool is_pad = false, is_zero = false;
             if (g < cnt) {
-                const float4 gb = s_gt[g];
-                const float2 ga = s_ga[g];
+                const float4 gb = s_row[g].box;
+                const float2 ga = make_float2(s_row[g].area, s_row[g].pad);
                 is_pad = ga.y != 0.0f;
                 is_zero = !is_pad && can_skip_zero && ga.x >= 0.0f &&
                           (gb.x >= wx1 || gb.z <= wx0 || gb.y >= wy1 || gb.w <= wy0);
@@ -253,10 +268,10 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
             const bool keep = g < cnt && !is_pad && !is_zero;
             const uint64_t mk = __ballot(keep), mz = __ballot(is_zero), mp = __ballot(is_pad);
             {
-                const float ga_x = s_ga[min(g, cnt - 1)].x;
+                const float ga_x = s_row[min(g, cnt - 1)].area;
                 odd_rows |= __ballot(keep && !(ga_x >= 0.0f && ga_x < INFINITY));
             }
-            if (keep) s_list[wave][nlist + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)g;
+            if (keep) s_list[wave][nlist + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = (ListEntry)(g * (int)sizeof(GtRow));
             nlist += (uint32_t)__popcll(mk);
             if (first_zero < 0 && mz != 0ull) first_zero = g0 + gs + __ffsll((unsigned long long)mz) - 1;
             if (first_pad < 0 && mp != 0ull) first_pad = g0 + gs + __ffsll((unsigned long long)mp) - 1;
@@ -275,11 +290,14 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
         // ---- the usual case, division-free: every area in play is finite and >= 0, so every IoU is a number >= +0
         // (an intersection is at most the smaller area, hence finite; a sum of areas that overflows gives 0) --------
         // The correctly rounded division is 13 of the ~29 issue cycles of a pair, and all the argmax needs
-        // from it is "which row has the greatest quotient".  q = i * rcp(u) is within 2^-22 of the true ratio
-        // (v_rcp_f32: 1 ulp), the rounded quotients within 2^-24: two rows whose q differ by more than 2^-19
-        // relative compare the same way as their exact quotients.  So the loop keeps the TWO largest q of the
-        // chunk (and the exact best of the chunks before it) -- a compare, a select, one v_med3 and one v_max per row,
-        // no band arithmetic -- and only when the runner-up ends inside that band of the winner (a tie, or next to
+        // from it is "which row has the greatest quotient".  q = i * rcp(u'), u' = ((a + 1e-8) + g) - i: the union
+        // summed in another order than bndbox.py:289 (one addition less per row: a + 1e-8 is the lane's constant).
+        // With u = 2^-24: i is the same number in both; no sum here cancels (a + g - i >= (a + g) / 2), so u' is within
+        // 5u of the real union and the reference's rounded union within 4u; v_rcp_f32 is 1 ulp (2u), the product u:
+        // q is within 13u of the reference's rounded quotient.  Two rows whose q differ by more than 2^-18 = 64u
+        // relative therefore compare the same way as their exact quotients.  So the loop keeps the TWO largest q of
+        // the chunk (and the exact best of the chunks before it) -- a compare, a select, one v_med3 and one v_max per
+        // row, no band arithmetic -- and only when the runner-up ends inside that band of the winner (a tie, or next to
         // one: practically never) is the chunk's list walked again with the exact IEEE divisions.  i == 0 is the exact
         // quotient +0 and 0 is never inside the band of 0 (strict >, first maximum wins).  The best row's exact IoU is
         // computed once, after the loop.  Same argmax and the same value as the exact loop below
@@ -294,14 +312,16 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
             }
         };
         if (can_skip_zero && odd_rows == 0ull && nlist != 0u) {
-            constexpr float BAND_HI = 1.0f + 0x1p-19f;
+            constexpr float BAND_HI = 1.0f + 0x1p-18f;
+            const float a_eps = a_area + 1e-8f;
             auto exact_iou = [&](int row) {
-                const float4 bb = row >= g0 ? s_gt[row - g0] : gtb[row];
+                const float4 bb = row >= g0 ? s_row[row - g0].box : gtb[row];
                 return pair_iou(a, a_area, bb, (bb.w - bb.y) * (bb.z - bb.x));
             };
             // best so far as an approximate quotient (-inf = none yet, 0 = an exact zero) and the runner-up
             float qb = best_iou, q2 = -INFINITY;
             const int best_in = best;
+            int best_off = -1;                                 // the chunk's best row as its offset in s_row, -1 = none beats `best`
             const float best_iou_in = best_iou;
             // R rows at a time.  The wave runs beside five or six others and its own chain of LDS round trips (list entry
             // -> box -> arithmetic, row after row as hipcc schedules it when left alone) is what bounds the loop, not the
@@ -314,8 +334,8 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
                 float g_area[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    gb[r] = s_gt[g[r]];
-                    g_area[r] = s_ga[g[r]].x;
+                    gb[r] = row_at(g[r]).box;
+                    g_area[r] = row_at(g[r]).area;
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // (two rows per v_pk_add_f32 / v_pk_mul_f32 were tried for the subtractions, products and sums: same-box
@@ -326,12 +346,12 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
                     const float ix0 = vmax(a.x, gb[r].x), ix1 = vmin(a.z, gb[r].z);
                     const float iy0 = vmax(a.y, gb[r].y), iy1 = vmin(a.w, gb[r].w);
                     ia[r] = vmax(ix1 - ix0, 0.0f) * vmax(iy1 - iy0, 0.0f);
-                    ua[r] = ((a_area + g_area[r]) - ia[r]) + 1e-8f;                      // bndbox.py:289, > 0 here
+                    ua[r] = (a_eps + g_area[r]) - ia[r];            // bndbox.py:289 with the 1e-8 added first (see above), > 0 here
                     q[r] = ia[r] * __builtin_amdgcn_rcpf(ua[r]);
                 }
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    best = q[r] > qb ? g0 + g[r] : best;                   // strict: the first of equal quotients stays
+                    best_off = q[r] > qb ? g[r] : best_off;                // strict: the first of equal quotients stays
                     q2 = __builtin_amdgcn_fmed3f(q[r], qb, q2);            // q2 <= qb: the median is the new runner-up
                     qb = vmax(qb, q[r]);
                 }
@@ -342,7 +362,7 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
                     bool any_reach = false;
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        const float cur = __uint_as_float(reinterpret_cast<const uint32_t *>(&s_gbest[g[r]])[1] & 0x7fffffffu);
+                        const float cur = __uint_as_float(reinterpret_cast<const uint32_t *>(&s_gbest[g[r] / (int)sizeof(GtRow)])[1] & 0x7fffffffu);
                         reach[r] = ia[r] > 0.0f && q[r] * BAND_HI >= cur;
                         any_reach = any_reach || reach[r];
                     }
@@ -364,8 +384,8 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
                             // a lane below the band of the wave's maximum has a strictly smaller exact IoU than the lane
                             // that holds it; the others (one lane, unless anchors tie) divide exactly and post
                             if (reach[r] && live && q[r] * BAND_HI >= qmax) {
-                                const float v = ia[r] / ua[r];
-                                if (v > 0.0f) atomicMax(&s_gbest[g[r]], gbest_key(v, n));
+                                const float v = ia[r] / (((a_area + g_area[r]) - ia[r]) + 1e-8f);
+                                if (v > 0.0f) atomicMax(&s_gbest[g[r] / (int)sizeof(GtRow)], gbest_key(v, n));
                             }
                         }
                     }
@@ -397,11 +417,12 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
                 best = best_in;
                 best_iou = best_iou_in;
                 for (k = 0; k < nlist; ++k) {
-                    const int g = s_list[wave][k];
-                    const float v = pair_iou(a, a_area, s_gt[g], s_ga[g].x);
+                    const int g = (int)(s_list[wave][k] / sizeof(GtRow));
+                    const float v = pair_iou(a, a_area, s_row[g].box, s_row[g].area);
                     if (v > best_iou) { best_iou = v; best = g0 + g; }
                 }
             } else {
+                if (best_off >= 0) best = g0 + best_off / (int)sizeof(GtRow);
                 best_iou = exact_iou(best);
             }
             post_chunk();
@@ -409,9 +430,9 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
         }
 #pragma unroll 2
         for (uint32_t k = 0; k < nlist; ++k) {
-            const int g = s_list[wave][k];
-            const float4 gb = s_gt[g];
-            const float2 ga = s_ga[g];
+            const int g = (int)(s_list[wave][k] / sizeof(GtRow));
+            const float4 gb = s_row[g].box;
+            const float2 ga = make_float2(s_row[g].area, s_row[g].pad);
             const float v = pair_iou(a, a_area, gb, ga.x);               // never a padded row here
             if (v > best_iou) { best_iou = v; best = g0 + g; }           // tf.argmax: first max
             if (GTBEST) {
@@ -1621,16 +1642,32 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
     if (blocks > 0x7fffffffull) return fail(ODBOX_EINVAL, "odbox_match_encode: grid too large");
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(out_gt_best);
     const uint32_t bg = (uint32_t)B * (uint32_t)G;
-    // The streaming variant runs SIX one-wave blocks per CU, not the ten its 14.6 KB of LDS would allow: unused dynamic
-    // LDS pads every block to a sixth of the CU's 160 KB (26 880 B in 1 280-B granules).  A store stream into cold
-    // memory is fastest when few tiles are being written at once: same-box A/B on the configs[2] share (2.26 GB per
-    // launch), resident blocks per CU 10 / 8 / 6 / 5 / 4: 349 / 344 / 325-329 / 325-329 / 364 us; the configs[1] batch
-    // into cold buffers 43.4 -> 43.0 us; more blocks per CU (GT staging cut to 128 rows: 32 per CU) 45.3 and 360 us.
-#ifndef ODBOX_ME_STREAM_PAD_KB
-#define ODBOX_ME_STREAM_PAD_KB 12
+    // The streaming variant runs FIVE one-wave blocks per CU, not the eight its 19.7 KB of LDS would allow: unused dynamic
+    // LDS pads every block to 28 160 B (22 granules of 1 280 B; six of them do not fit the CU's 160 KB).  A store stream
+    // into cold memory is fastest when few tiles are being written at once: same-box A/B on the configs[2] share (2.26 GB
+    // per launch), resident blocks per CU 10 / 8 / 6 / 5 / 4: 349 / 344 / 325-329 / 325-329 / 364 us in round 2; with the
+    // round-3 matcher 6 / 5 / 4: 328-338 / 321-326 / 362-364 us on one box, 330 / 321 on another (5 wins by 1-3 %); the
+    // configs[1] batch into cold buffers 43.4 -> 43.0 us; more blocks per CU (GT staging cut to 128 rows: 32 per CU) 45.3
+    // and 360 us.
+#ifndef ODBOX_ME_STREAM_BLOCK_LDS
+#define ODBOX_ME_STREAM_BLOCK_LDS 28160
 #endif
-    const size_t pad_lds = stream_out ? (size_t)ODBOX_ME_STREAM_PAD_KB * 1024 : 0;
+    auto stream_pad = [&](auto kernel, int which) -> size_t {
+        if (!stream_out) return 0;
+        // static LDS of the instantiation, asked once each (it moves with ME_GCHUNK and the matcher's staging layout;
+        // the two streaming instantiations share a signature, hence the index)
+        static std::atomic<size_t> fixed_lds[2];
+        size_t fixed = fixed_lds[which].load(std::memory_order_relaxed);
+        if (fixed == 0) {
+            hipFuncAttributes at{};
+            fixed = hipFuncGetAttributes(&at, reinterpret_cast<const void *>(kernel)) == hipSuccess && at.sharedSizeBytes
+                        ? (size_t)at.sharedSizeBytes : (size_t)ODBOX_ME_STREAM_BLOCK_LDS;
+            fixed_lds[which].store(fixed, std::memory_order_relaxed);
+        }
+        return fixed < (size_t)ODBOX_ME_STREAM_BLOCK_LDS ? (size_t)ODBOX_ME_STREAM_BLOCK_LDS - fixed : 0;
+    };
     auto launch = [&](auto kernel) {
+        const size_t pad_lds = stream_pad(kernel, 0);
         hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(tile), pad_lds, (hipStream_t)stream,
                            (const float4 *)anchors, (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w,
                            neg_thr, pos_thr, out_regression, out_labels, out_match_idx, out_state, out_max_iou,
@@ -1673,6 +1710,7 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
     while (gcd(mult, tiles) != 1) mult += 2;
     if (train_tuning_env("ODBOX_GTBEST_LINEAR")) mult = 1;
     auto launch_best = [&](auto kernel) {
+        const size_t pad_lds = stream_pad(kernel, 1);
         hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(tile), pad_lds, (hipStream_t)stream,
                            (const float4 *)anchors, (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w,
                            neg_thr, pos_thr, out_regression, out_labels, out_match_idx, out_state, out_max_iou,

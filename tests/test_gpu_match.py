@@ -325,3 +325,31 @@ def test_ties_and_near_ties_in_the_division_free_matcher():
     ref = c_oracle.match_encode(anchors, (256, 256), big, lab2, 1, threads=4, dense=False)
     np.testing.assert_array_equal(cpu(got['match_idx']), ref['match_idx'])
     np.testing.assert_array_equal(cpu(got['max_iou']).view(np.uint32), ref['max_iou'].view(np.uint32))
+
+
+def test_many_gt_rows_take_the_tile_major_order_and_tiny_boxes_keep_the_epsilon():
+    """More than 64 GT rows into a small output run the tiles of ALL images coarse-first (tile-major order: B >= 8,
+    here 9 images and a ragged last tile), and the division-free matcher sums the union as ((a + 1e-8) + g) - i.  Boxes
+    of 1e-4 pixels make the 1e-8 a visible part of every union, zero-area anchors and rows included; argmax, state
+    and the max IoU must be the oracle's bit for bit at both scales."""
+    rng = np.random.default_rng(77)
+    F = np.float32
+    base = O.generate_anchors(128)[:3001]
+    for scale in (1.0, 1e-4 / 32.0):
+        anchors = (base * F(scale)).astype(F)
+        anchors[5] = anchors[4]                                          # equal anchors
+        anchors[17, 2:] = anchors[17, :2]                                # a zero-area anchor
+        gt = (np.stack([workloads.gt_boxes(rng, 128, 70, 3)[0] for _ in range(9)]) * F(scale)).astype(F)
+        gt[:, 7] = gt[:, 3]                                              # duplicates: the first must win
+        gt[:, 9, 2:] = gt[:, 9, :2]                                      # a zero-area row
+        gt[2, 60:] = -1.0                                                # padded tail in one image
+        lab = rng.integers(0, 3, gt.shape[:2]).astype(np.int32)
+        size = (128 * scale, 128 * scale)
+        got = A.match_encode(anchors, size, gt, lab, 3, dense=True, compact=True)
+        assert A.match_encode_last_plan() == 'tiles'
+        ref = c_oracle.match_encode(anchors, size, gt, lab, 3, threads=4, dense=True)
+        np.testing.assert_array_equal(cpu(got['match_idx']), ref['match_idx'])
+        np.testing.assert_array_equal(cpu(got['state']), ref['state'])
+        np.testing.assert_array_equal(cpu(got['max_iou']).view(np.uint32), ref['max_iou'].view(np.uint32))
+        np.testing.assert_array_equal(cpu(got['regression']), ref['regression'])          # (NaN offsets of the zero-area anchor compare equal)
+        np.testing.assert_array_equal(cpu(got['labels']), ref['labels'])
