@@ -394,7 +394,7 @@ def main():
                 # how busy the VALUs are over the launch (SQ counters, collected in their own PMC passes).
                 # `frac`: the matcher's EVALUATED work against the FMA-free fp32 VALU rate, from this run's time.
                 # Pairs per launch are a constant of the seeded workload (tools/count_pairs.py, a counting build);
-                # 27.25 issue slots per pair is the four-row loop's disassembly (93 full-rate VALU instructions + 4
+                # 21.25 issue slots per pair is the four-row loop's disassembly (69 full-rate VALU instructions + 4
                 # quarter-rate v_rcp_f32 per four rows).  39.3 T lane-ops/s = 256 CUs x 64 lanes x 2.4 GHz (no FMA: the
                 # path may not contract); the packed ceiling is twice that.  SURVEY.md 8d's nominal figure (every one of
                 # the 3.1 G pairs at 16 ops) exceeds 1 because nine pairs in ten are proven zero, not evaluated.
