@@ -186,9 +186,9 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
 {
     __shared__ unsigned long long s_gbest[GTBEST ? ME_GCHUNK : 1];
     __shared__ unsigned long long s_gseed[GTBEST ? ME_GCHUNK : 1];
-    // one staged GT row: box, area, 1.0 if padded row else 0.0 -- 32 bytes, so that one LDS address serves the box
-    // (ds_read_b128) and the area (ds_read_b32 at +16)
-    struct __align__(16) GtRow { float4 box; float area; float pad; float spare[2]; };
+    // one staged GT row: box, area, kind (0 = a box with a finite area >= 0, 1 = padded row, 2 = any other area: negative,
+    // infinite, NaN) -- 32 bytes, so that one LDS address serves the box (ds_read_b128) and the area (ds_read_b32 at +16)
+    struct __align__(16) GtRow { float4 box; float area; float kind; float spare[2]; };
     __shared__ GtRow s_row[ME_GCHUNK];
     // per wave: the GT rows it must evaluate, as BYTE OFFSETS into s_row (row * 32: the matcher loop spends no VALU
     // instruction on addresses, and the best row is carried as its offset), + slack for the read-ahead
@@ -237,7 +237,7 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
             float gmax = vmax(vmax(gb.x, gb.y), vmax(gb.z, gb.w));    // bndbox.py:295
             s_row[g].box = gb;
             s_row[g].area = area;
-            s_row[g].pad = gmax < 0.0f ? 1.0f : 0.0f;
+            s_row[g].kind = gmax < 0.0f ? 1.0f : (area >= 0.0f && area < INFINITY) ? 0.0f : 2.0f;
             if (GTBEST) {
                 // device scope: a plain load would be served by this XCD's L2, which never sees the other XCDs' atomics
                 const unsigned long long seed = __hip_atomic_load(&gbest_keys[(size_t)b * G + g0 + g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -255,22 +255,20 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
         // this wave's work list: 64 GT rows per step, one per lane, order preserved
         uint32_t nlist = 0;
         uint64_t odd_rows = 0ull;                          // listed rows whose area is negative, infinite or NaN
+        // (branch-free on purpose: written with an `if (g < cnt)` around the reads, hipcc made three dependent LDS round
+        // trips and four exec-mask branches of every step; the clamped row of a lane beyond the chunk is read and ignored)
         for (int gs = 0; gs < cnt; gs += WAVE) {
             const int g = gs + (int)lane;
-            bool is_pad = false, is_zero = false;
-            if (g < cnt) {
-                const float4 gb = s_row[g].box;
-                const float2 ga = make_float2(s_row[g].area, s_row[g].pad);
-                is_pad = ga.y != 0.0f;
-                is_zero = !is_pad && can_skip_zero && ga.x >= 0.0f &&
-                          (gb.x >= wx1 || gb.z <= wx0 || gb.y >= wy1 || gb.w <= wy0);
-            }
-            const bool keep = g < cnt && !is_pad && !is_zero;
+            const GtRow &row = s_row[min(g, cnt - 1)];
+            const float4 gb = row.box;
+            const float kind = row.kind;
+            const bool in = g < cnt;
+            const bool outside = (gb.x >= wx1) | (gb.z <= wx0) | (gb.y >= wy1) | (gb.w <= wy0);
+            const bool is_pad = in & (kind == 1.0f);
+            const bool is_zero = in & (kind == 0.0f) & can_skip_zero & outside;
+            const bool keep = in & !is_pad & !is_zero;
             const uint64_t mk = __ballot(keep), mz = __ballot(is_zero), mp = __ballot(is_pad);
-            {
-                const float ga_x = s_row[min(g, cnt - 1)].area;
-                odd_rows |= __ballot(keep && !(ga_x >= 0.0f && ga_x < INFINITY));
-            }
+            odd_rows |= __ballot(keep & (kind == 2.0f));
             if (keep) s_list[wave][nlist + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = (ListEntry)(g * (int)sizeof(GtRow));
             nlist += (uint32_t)__popcll(mk);
             if (first_zero < 0 && mz != 0ull) first_zero = g0 + gs + __ffsll((unsigned long long)mz) - 1;
@@ -432,7 +430,7 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
         for (uint32_t k = 0; k < nlist; ++k) {
             const int g = (int)(s_list[wave][k] / sizeof(GtRow));
             const float4 gb = s_row[g].box;
-            const float2 ga = make_float2(s_row[g].area, s_row[g].pad);
+            const float2 ga = make_float2(s_row[g].area, s_row[g].kind);
             const float v = pair_iou(a, a_area, gb, ga.x);               // never a padded row here
             if (v > best_iou) { best_iou = v; best = g0 + g; }           // tf.argmax: first max
             if (GTBEST) {
