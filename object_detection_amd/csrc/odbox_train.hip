@@ -262,13 +262,17 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
             const GtRow &row = s_row[min(g, cnt - 1)];
             const float4 gb = row.box;
             const float kind = row.kind;
-            const bool in = g < cnt;
+            // the wave's masks as 64-bit integers built from the elementary compares (a ballot of a combined predicate
+            // makes hipcc materialise it in a VGPR and compare it again); `keep` per lane for the store below
+            const bool in = g < cnt, k0 = kind == 0.0f, k1 = kind == 1.0f;
             const bool outside = (gb.x >= wx1) | (gb.z <= wx0) | (gb.y >= wy1) | (gb.w <= wy0);
-            const bool is_pad = in & (kind == 1.0f);
-            const bool is_zero = in & (kind == 0.0f) & can_skip_zero & outside;
-            const bool keep = in & !is_pad & !is_zero;
-            const uint64_t mk = __ballot(keep), mz = __ballot(is_zero), mp = __ballot(is_pad);
-            odd_rows |= __ballot(keep & (kind == 2.0f));
+            const uint64_t m_in = __ballot(in);
+            const uint64_t m_out = __ballot(gb.x >= wx1) | __ballot(gb.z <= wx0) | __ballot(gb.y >= wy1) | __ballot(gb.w <= wy0);
+            const uint64_t mp = m_in & __ballot(k1);
+            const uint64_t mz = can_skip_zero ? m_in & __ballot(k0) & m_out : 0ull;
+            const uint64_t mk = m_in & ~mp & ~mz;
+            odd_rows |= mk & __ballot(kind == 2.0f);
+            const bool keep = in & !k1 & !(k0 & can_skip_zero & outside);
             if (keep) s_list[wave][nlist + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = (ListEntry)(g * (int)sizeof(GtRow));
             nlist += (uint32_t)__popcll(mk);
             if (first_zero < 0 && mz != 0ull) first_zero = g0 + gs + __ffsll((unsigned long long)mz) - 1;
