@@ -1806,8 +1806,11 @@ static int match_loss_run(const char *name, const float *anchors, const float *g
     const bool g15 = gamma == 1.5f;                 // the reference's default: pow as x * sqrt(x)
     const bool al = d % PredIO<T>::VEC == 0 && aligned16(pred_scores);
     float *partials = out_loss ? (float *)workspace : nullptr;
+    // (tuning builds: ODBOX_LOSS_PAD bytes of unused dynamic LDS = fewer resident blocks per CU; see profiles/README.md)
+    const char *pad_env = train_tuning_env("ODBOX_LOSS_PAD");
+    const size_t pad_lds = pad_env ? (size_t)atoi(pad_env) : 0;
     auto launch = [&](auto kernel, box_t *gb, T *gs) {
-        hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(ME_TILE), 0, st, (const float4 *)anchors,
+        hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(ME_TILE), pad_lds, st, (const float4 *)anchors,
                            (const float4 *)gt_boxes, gt_labels, N, G, C, img_h, img_w, neg_thr, pos_thr,
                            (const box_t *)pred_boxes, pred_scores, lp, gsc, gb, gs, partials, (uint32_t)tiles,
                            magic);
