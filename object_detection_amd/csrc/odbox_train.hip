@@ -70,9 +70,12 @@ __device__ __forceinline__ float pair_iou(const float4 a, float a_area, const fl
 // Fused matcher + encoder: anchors.py:116-213 (+ :215-274, :277-299, bndbox.py:254-299).
 //
 // One block = one tile of ME_TILE anchors of one image.
-//   phase 1  thread = anchor: GT boxes of the image staged in LDS (box, area, pad flag) in
-//            chunks of ME_GCHUNK, per-wave culling of the rows that cannot overlap, IoU +
-//            strict-> argmax in registers (first max wins).
+//   phase 1  thread = anchor: GT boxes of the image staged in LDS (32-byte records: box, area, kind of row)
+//            in chunks of ME_GCHUNK; per-wave culling of the rows that cannot overlap into a work list of
+//            record offsets (branch-free, one LDS round trip per 64 rows); then the division-free loop over
+//            the list, four rows per step: approximate quotients, the two largest kept, the exact IEEE
+//            divisions only for the winner and for a chunk whose runner-up is inside the winner's error band
+//            (first max wins, bit for bit the reference's argmax and IoU).
 //   phase 2  thresholds, out-of-image test, label, offsets; compact outputs stored directly; the
 //            5 regression floats staged in LDS.
 //   phase 3  the two dense outputs of the tile are contiguous in memory ([tile,5] and
