@@ -161,7 +161,7 @@ struct TileMatch {
 // "can my approximate quotient, at the top of its error band, reach the row's best so far".  Only a
 // wave with such a lane goes on: DPP / readlane reduction of the quotient over the wavefront, the
 // lanes within the band of the wave's maximum (one, unless anchors tie) take the exact IEEE division
-// and fold their key into the row's LDS maximum.  Per chunk each row whose key rose above its seed
+// and fold their key into the row's LDS maximum (kept in the staged row's record).  Per chunk each row some lane posted for
 // goes to gbest_keys[b, g] with one global atomicMax.  Pairs with IoU exactly +0 (culled rows
 // included) post nothing: a row nobody posted for has IoU +0 everywhere (or -1: padding) and its
 // argmax is anchor 0 -- filled in by gt_best_finalize_kernel, which also recomputes the winner's
@@ -187,17 +187,23 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
                                                 int G, int C, float img_h, float img_w, float neg_thr, float pos_thr,
                                                 EarlyWork early, unsigned long long *gbest_keys = nullptr)
 {
-    __shared__ unsigned long long s_gbest[GTBEST ? ME_GCHUNK : 1];
-    __shared__ unsigned long long s_gseed[GTBEST ? ME_GCHUNK : 1];
+    __shared__ uint32_t s_dirty[GTBEST ? ME_GCHUNK / 32 : 1];      // GTBEST: rows some lane of this block posted a key for
     // one staged GT row: box, area, kind (0 = a box with a finite area >= 0, 1 = padded row, 2 = any other area: negative,
-    // infinite, NaN) -- 32 bytes, so that one LDS address serves the box (ds_read_b128) and the area (ds_read_b32 at +16)
-    struct __align__(16) GtRow { float4 box; float area; float kind; float spare[2]; };
+    // infinite, NaN) and, for GTBEST, the row's best key so far -- 32 bytes, so that one LDS address serves the box
+    // (ds_read_b128), the area (ds_read_b32 at +16) and the key's upper word (ds_read_b32 at +28)
+    struct __align__(16) GtRow { float4 box; float area; float kind; unsigned long long key; };
     __shared__ GtRow s_row[ME_GCHUNK];
     // per wave: the GT rows it must evaluate, as BYTE OFFSETS into s_row (row * 32: the matcher loop spends no VALU
     // instruction on addresses, and the best row is carried as its offset), + slack for the read-ahead
     __shared__ __align__(16) ListEntry s_list[TILE / WAVE][ME_GCHUNK + FAST_ROWS];
     static_assert(sizeof(GtRow) == 32 && (size_t)ME_GCHUNK * sizeof(GtRow) <= (size_t)(ListEntry)~(ListEntry)0 + 1, "list entries are byte offsets of 32-byte rows");
     auto row_at = [&](uint32_t off) -> const GtRow & { return *reinterpret_cast<const GtRow *>(reinterpret_cast<const char *>(s_row) + off); };
+    constexpr int GCHUNK_WORDS = ME_GCHUNK / 32;
+    // GTBEST: fold a key into the staged row's maximum and mark the row for the chunk's global atomicMax
+    auto post_key = [&](int g, unsigned long long key) {
+        atomicMax(&s_row[g].key, key);
+        atomicOr(&s_dirty[g >> 5], 1u << (g & 31));
+    };
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const uint32_t n = n0 + tid;
@@ -244,8 +250,8 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
             if (GTBEST) {
                 // device scope: a plain load would be served by this XCD's L2, which never sees the other XCDs' atomics
                 const unsigned long long seed = __hip_atomic_load(&gbest_keys[(size_t)b * G + g0 + g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_gbest[g] = seed;
-                s_gseed[g] = seed;
+                s_row[g].key = seed;
+                if (g < GCHUNK_WORDS) s_dirty[g] = 0u;
             }
         }
         // every global load issued so far has been consumed: from here to the label / box gathers at
@@ -312,8 +318,7 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
             __syncthreads();                                 // every wave's maxima of this chunk are in
             unsigned long long *dst = gbest_keys + (size_t)b * G + g0;
             for (int g = tid; g < cnt; g += TILE) {
-                const unsigned long long k = s_gbest[g];
-                if (k > s_gseed[g]) atomicMax(&dst[g], k);
+                if ((s_dirty[g >> 5] >> (g & 31)) & 1u) atomicMax(&dst[g], s_row[g].key);
             }
         };
         if (can_skip_zero && odd_rows == 0ull && nlist != 0u) {
@@ -367,7 +372,7 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
                     bool any_reach = false;
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        const float cur = __uint_as_float(reinterpret_cast<const uint32_t *>(&s_gbest[g[r] / (int)sizeof(GtRow)])[1] & 0x7fffffffu);
+                        const float cur = __uint_as_float(reinterpret_cast<const uint32_t *>(&row_at(g[r]).key)[1] & 0x7fffffffu);
                         reach[r] = ia[r] > 0.0f && q[r] * BAND_HI >= cur;
                         any_reach = any_reach || reach[r];
                     }
@@ -390,7 +395,7 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
                             // that holds it; the others (one lane, unless anchors tie) divide exactly and post
                             if (reach[r] && live && q[r] * BAND_HI >= qmax) {
                                 const float v = ia[r] / (((a_area + g_area[r]) - ia[r]) + 1e-8f);
-                                if (v > 0.0f) atomicMax(&s_gbest[g[r] / (int)sizeof(GtRow)], gbest_key(v, n));
+                                if (v > 0.0f) post_key(g[r] / (int)sizeof(GtRow), gbest_key(v, n));
                             }
                         }
                     }
@@ -442,7 +447,7 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
             if (v > best_iou) { best_iou = v; best = g0 + g; }           // tf.argmax: first max
             if (GTBEST) {
                 const bool forced = !can_skip_zero || !(ga.x >= 0.0f);
-                if (live && (v > 0.0f || forced)) atomicMax(&s_gbest[g], gbest_key(v, n));
+                if (live && (v > 0.0f || forced)) post_key(g, gbest_key(v, n));
             }
         }
         post_chunk();
@@ -515,6 +520,9 @@ __global__ __launch_bounds__(STREAM ? ME_TILE_STREAM : ME_TILE_ENC) void match_e
     const uint32_t b = tile_major ? blk % n_img : blk / tiles_per_image;
     // (GTBEST: `remap` carries a multiplier coprime to tiles_per_image -- the tiles of an image in a scattered order: a
     // sweep through the anchor grid approaches every GT box step by step, and every step raises its best)
+    // (the scatter is worth a third of the launch and its details a tenth: configs[3] with the per-GT output 382 us; the
+    // same multiplier walked from the other end 421 us; the coarse tiles first -- they walk every GT row -- and the rest
+    // scattered 455 us; tiles in order 540 us)
     const uint32_t n0 = (GTBEST ? (uint32_t)(((uint64_t)(blk / n_img) * remap) % tiles_per_image)
                                 : tile_major ? blk / n_img : blk - b * tiles_per_image) * TILE;
     const uint32_t n = n0 + tid;
@@ -1714,6 +1722,7 @@ int odbox_match_encode(const float *anchors, const float *gt_boxes, const int32_
     auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
     while (gcd(mult, tiles) != 1) mult += 2;
     if (train_tuning_env("ODBOX_GTBEST_LINEAR")) mult = 1;
+    if (const char *e = train_tuning_env("ODBOX_GTBEST_MULT")) mult = (uint32_t)atoi(e);        // (must be coprime to the tile count)
     auto launch_best = [&](auto kernel) {
         const size_t pad_lds = stream_pad(kernel, 1);
         hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(tile), pad_lds, (hipStream_t)stream,
