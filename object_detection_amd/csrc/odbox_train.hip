@@ -221,14 +221,30 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
     // every live anchor of the wave has a finite area >= 0 (false for a negative, infinite or NaN area: the
     // comparisons are ordered ones and the unit is built with NaNs honoured)
     const bool can_skip_zero = __ballot(live && !(a_area >= 0.0f && a_area < INFINITY)) == 0ull;
+    // over the wavefront by DPP -- quads, half rows, rows, then row 0 into 1 and 2 into 3, then 1 into 2 and 3: lane 63 holds
+    // the four results -- 24 VALU instructions and no LDS round trip (the butterfly of __shfl_xor was 24 ds_bpermute in six
+    // dependent round trips at the head of every block's critical path).  One statement, the four chains interleaved:
+    // a DPP read of a VGPR needs two wait states after its write, and every chain's next step comes four instructions later.
     auto reduce_box = [&] {
-#pragma unroll
-        for (int off = 1; off < WAVE; off <<= 1) {
-            wx0 = vmin(wx0, __shfl_xor(wx0, off));
-            wy0 = vmin(wy0, __shfl_xor(wy0, off));
-            wx1 = vmax(wx1, __shfl_xor(wx1, off));
-            wy1 = vmax(wy1, __shfl_xor(wy1, off));
-        }
+#define ODBOX_BOX_STEP(ctrl)                                        \
+        "v_min_f32_dpp %0, %0, %0 " ctrl " bank_mask:0xf\n"          \
+        "v_min_f32_dpp %1, %1, %1 " ctrl " bank_mask:0xf\n"          \
+        "v_max_f32_dpp %2, %2, %2 " ctrl " bank_mask:0xf\n"          \
+        "v_max_f32_dpp %3, %3, %3 " ctrl " bank_mask:0xf\n"
+        asm volatile("s_nop 1\n"
+                     ODBOX_BOX_STEP("quad_perm:[1,0,3,2] row_mask:0xf")
+                     ODBOX_BOX_STEP("quad_perm:[2,3,0,1] row_mask:0xf")
+                     ODBOX_BOX_STEP("row_half_mirror row_mask:0xf")
+                     ODBOX_BOX_STEP("row_mirror row_mask:0xf")
+                     ODBOX_BOX_STEP("row_bcast:15 row_mask:0xa")
+                     ODBOX_BOX_STEP("row_bcast:31 row_mask:0xc")
+                     "s_nop 1"
+                     : "+v"(wx0), "+v"(wy0), "+v"(wx1), "+v"(wy1));
+#undef ODBOX_BOX_STEP
+        wx0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wx0), 63));
+        wy0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wy0), 63));
+        wx1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wx1), 63));
+        wy1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wy1), 63));
     };
     if (!REDUCE_LATE) reduce_box();
 

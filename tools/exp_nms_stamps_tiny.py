@@ -8,7 +8,7 @@ lib = _lib.load(); dev = _lib.require_gpu()
 S, B, C = 512, 64, 90
 anchors = A.generate_anchors(A.AnchorsConfig(), S); an = anchors.cpu().numpy()
 rng = np.random.default_rng(7)
-reg8, sc8 = E.make(an, 8, C, int(sys.argv[1]), int(sys.argv[2]), 0.03, rng)
+reg8, sc8 = E.make(an, 8, C, int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3]) if len(sys.argv) > 3 else 0.03, rng)
 reg = torch.as_tensor(np.tile(reg8, (8, 1, 1))).to(dev); sc = torch.as_tensor(np.tile(sc8, (8, 1, 1))).to(dev)
 arr = (ctypes.c_ulonglong * 64); s, m, n = arr(), arr(), arr()
 for _ in range(3): BB.decode_and_nms(anchors, reg, sc, (S, S))
