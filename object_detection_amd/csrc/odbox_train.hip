@@ -1297,13 +1297,28 @@ __global__ __launch_bounds__(ME_TILE) void match_loss_kernel(
     }
 
     // ---- block partial sums (wave shuffle, then one thread adds the 4 wave sums in order) ------
+    // (by DPP like the matcher's bounding box: quads, half rows, rows, row 0 into 1 and 2 into 3, 1 into 3 -- lane 63 holds
+    // the wave's four sums; a fixed order, so the sums are the same bits run after run.  Six __shfl_down steps per sum were
+    // 24 ds_bpermute in six dependent LDS round trips at the tail of every block.)
     float v3[4] = {cls, dist, npos, hit};
+#define ODBOX_SUM_STEP(ctrl)                                        \
+    "v_add_f32_dpp %0, %0, %0 " ctrl " bank_mask:0xf\n"              \
+    "v_add_f32_dpp %1, %1, %1 " ctrl " bank_mask:0xf\n"              \
+    "v_add_f32_dpp %2, %2, %2 " ctrl " bank_mask:0xf\n"              \
+    "v_add_f32_dpp %3, %3, %3 " ctrl " bank_mask:0xf\n"
+    asm volatile("s_nop 1\n"
+                 ODBOX_SUM_STEP("quad_perm:[1,0,3,2] row_mask:0xf")
+                 ODBOX_SUM_STEP("quad_perm:[2,3,0,1] row_mask:0xf")
+                 ODBOX_SUM_STEP("row_half_mirror row_mask:0xf")
+                 ODBOX_SUM_STEP("row_mirror row_mask:0xf")
+                 ODBOX_SUM_STEP("row_bcast:15 row_mask:0xa")
+                 ODBOX_SUM_STEP("row_bcast:31 row_mask:0xc")
+                 "s_nop 1"
+                 : "+v"(v3[0]), "+v"(v3[1]), "+v"(v3[2]), "+v"(v3[3]));
+#undef ODBOX_SUM_STEP
+    if ((tid & 63u) == 63u) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float x = v3[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-        if ((tid & 63u) == 0) s_red[k][tid >> 6] = x;
+        for (int k = 0; k < 4; ++k) s_red[k][tid >> 6] = v3[k];
     }
     __syncthreads();
     if (tid < 4 && partials) {
