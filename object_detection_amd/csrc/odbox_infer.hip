@@ -678,6 +678,47 @@ constexpr uint32_t TIER_BUCKETS = 1024;                   // score histogram of 
 
 constexpr int PART_REG = 16;                              // keys per thread that a partition block holds in registers
 
+// Wavefront reductions and scans by DPP: no LDS round trips (a __shfl is a ds_bpermute, and six dependent ones are a
+// third of a microsecond in blocks whose whole life is ten).  Lanes a control leaves unwritten take `old`.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND = false>
+__device__ __forceinline__ int dpp_i(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, ROW_MASK, BANK_MASK, BOUND); }
+// inclusive prefix sum over the 64 lanes: three shifts inside the quads' reach, rows of 16, then row 0 -> 1, 2 -> 3, 1 -> 2 and 3
+__device__ __forceinline__ int wave_incl_scan(int x)
+{
+    int s = x + dpp_i<0x111, 0xf, 0xf, true>(0, x);        // row_shr:1
+    s += dpp_i<0x112, 0xf, 0xf, true>(0, x);               // row_shr:2
+    s += dpp_i<0x113, 0xf, 0xf, true>(0, x);               // row_shr:3
+    s += dpp_i<0x114, 0xf, 0xe>(0, s);                     // row_shr:4, lanes 4..15 of a row
+    s += dpp_i<0x118, 0xf, 0xc>(0, s);                     // row_shr:8, lanes 8..15
+    s += dpp_i<0x142, 0xa, 0xf>(0, s);                     // row_bcast:15 into rows 1 and 3
+    s += dpp_i<0x143, 0xc, 0xf>(0, s);                     // row_bcast:31 into rows 2 and 3
+    return s;
+}
+// minimum / maximum over the 64 lanes, wave-uniform: butterflies inside a row of 16, then the four rows through SGPRs
+template <bool MAX>
+__device__ __forceinline__ uint32_t wave_minmax_u32(uint32_t x)
+{
+    auto op = [](uint32_t a, uint32_t b) { return MAX ? max(a, b) : min(a, b); };
+    x = op(x, (uint32_t)dpp_i<0xB1, 0xf, 0xf, true>(0, (int)x));      // quad_perm [1,0,3,2]
+    x = op(x, (uint32_t)dpp_i<0x4E, 0xf, 0xf, true>(0, (int)x));      // quad_perm [2,3,0,1]
+    x = op(x, (uint32_t)dpp_i<0x141, 0xf, 0xf, true>(0, (int)x));     // row_half_mirror
+    x = op(x, (uint32_t)dpp_i<0x140, 0xf, 0xf, true>(0, (int)x));     // row_mirror
+    return op(op((uint32_t)__builtin_amdgcn_readlane((int)x, 0), (uint32_t)__builtin_amdgcn_readlane((int)x, 16)),
+              op((uint32_t)__builtin_amdgcn_readlane((int)x, 32), (uint32_t)__builtin_amdgcn_readlane((int)x, 48)));
+}
+// sum of s[0 .. n) for a wave-uniform n <= NW: NW independent broadcast reads issued together instead of n dependent trips
+template <int NW>
+__device__ __forceinline__ int sum_first(const int *s, uint32_t n)
+{
+    int v[NW];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) v[q] = s[q];
+    int acc = 0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) acc += (uint32_t)q < n ? v[q] : 0;
+    return acc;
+}
+
 // The tier of one image, by the whole block (THREADS threads; kreg = the image's keys, ~0 = none): marks every key
 // outside the tier ~0 and returns the tier's size.  The cut is found without a sort: a TIER_BUCKETS-bucket histogram
 // over the top bits of the (order-preserving) score word, the bucket in which the running count passes tier_k taken
@@ -698,11 +739,8 @@ __device__ __forceinline__ uint32_t tier_select(uint64_t (&kreg)[REG], uint32_t 
             lo = min(lo, sw);
             hi = max(hi, sw);
         }
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) {
-        lo = min(lo, (uint32_t)__shfl_xor((int)lo, off));
-        hi = max(hi, (uint32_t)__shfl_xor((int)hi, off));
-    }
+    lo = wave_minmax_u32<false>(lo);
+    hi = wave_minmax_u32<true>(hi);
     if ((tid & 63u) == 0u) {
         s_scan[tid >> 6] = (int)lo;
         s_scan[NW + (tid >> 6)] = (int)hi;
@@ -721,17 +759,11 @@ __device__ __forceinline__ uint32_t tier_select(uint64_t (&kreg)[REG], uint32_t 
     __syncthreads();
     // inclusive scan over the buckets, BPT per thread
     const int h0 = s_tier[BPT * tid], h1 = BPT == 2 ? s_tier[BPT * tid + 1u] : 0;
-    int incl = h0 + h1;
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) {
-        const int v = __shfl_up(incl, off);
-        if ((int)(tid & 63u) >= off) incl += v;
-    }
+    const int incl = wave_incl_scan(h0 + h1);
     __syncthreads();                         // the lo / hi slots of s_scan have been read by everybody
     if ((tid & 63u) == 63u) s_scan[tid >> 6] = incl;
     __syncthreads();
-    int before = incl - (h0 + h1);
-    for (uint32_t w = 0; w < (tid >> 6); ++w) before += s_scan[w];
+    const int before = incl - (h0 + h1) + sum_first<NW>(s_scan, tid >> 6);
     if ((uint32_t)before < tier_k) {         // exactly one thread finds the bucket the tier_k-th best falls into
         if ((uint32_t)(before + h0) >= tier_k) {
             s_tier[TIER_BUCKETS] = (int)(BPT * tid);
@@ -844,16 +876,10 @@ __device__ __forceinline__ void partition_image(
         biggest = max(biggest, n);
     }
     if (biggest > (int)NMS_SEG_LDS) s_scan[PART_THREADS] = 1;
-    int incl = local;
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) {
-        const int v = __shfl_up(incl, off);
-        if ((int)(tid & 63u) >= off) incl += v;
-    }
+    const int incl = wave_incl_scan(local);
     if ((tid & 63u) == 63u) s_scan[tid >> 6] = incl;
     __syncthreads();
-    int run = incl - local;
-    for (uint32_t w = 0; w < (tid >> 6); ++w) run += s_scan[w];
+    int run = incl - local + sum_first<PART_THREADS / WAVE>(s_scan, tid >> 6);
     int *seg = seg_start + (size_t)b * (C + 1);
     for (int c = c0; c < c1; ++c) {
         seg[c] = run;
@@ -1656,15 +1682,16 @@ __global__ __launch_bounds__(TT_THREADS, 5) void tier_tail_kernel(
         }
         whole = M <= tk;
         ODBOX_LAP(stp, 41, tid == 0);                         // keys loaded
+        // the class histogram (upper half of the region: the tier selection works in the lower half and nothing writes
+        // that half again before the scatter, three barriers on) is zeroed here, under the tier selection's own barriers
+        for (int c = tid; c < copies * C; c += TT_THREADS) s_hist[c] = 0;
         if (!whole) M = tier_select<TT_THREADS, TT_REG>(kreg, M, tk, s_tier, s_misc, tid);
+        else __syncthreads();
         ODBOX_LAP(stp, 42, tid == 0);                         // tier selected
         again = M > TT_CAP;                                   // (a run of equal scores at the tier's edge)
         if (again) break;
         {
-            __syncthreads();                                  // the tier histogram has been read by everybody
             // ---- class histogram, dense segment starts, scatter into LDS ------------------------------------
-            for (int c = tid; c < copies * C; c += TT_THREADS) s_hist[c] = 0;
-            __syncthreads();
             int *my_hist = s_hist + (int)(tid & (uint32_t)(copies - 1)) * C;
 #pragma unroll
             for (int r = 0; r < TT_REG; ++r)
@@ -1675,20 +1702,14 @@ __global__ __launch_bounds__(TT_THREADS, 5) void tier_tail_kernel(
             int local = 0;
             for (int c = c0; c < c1; ++c)
                 for (int k = 0; k < copies; ++k) local += s_hist[k * C + c];
-            int incl = local;
-#pragma unroll
-            for (int off = 1; off < WAVE; off <<= 1) {
-                const int v = __shfl_up(incl, off);
-                if ((int)lane >= off) incl += v;
-            }
+            const int incl = wave_incl_scan(local);
             if (lane == 63u) s_misc[wave] = incl;
             if (tid == 0) {
                 s_misc[32] = 0;
                 s_misc[33] = 0;
             }
             __syncthreads();
-            int run = incl - local;
-            for (uint32_t w = 0; w < wave; ++w) run += s_misc[w];
+            int run = incl - local + sum_first<TT_WAVES>(s_misc, wave);
             for (int c = c0; c < c1; ++c) {
                 s_start[c] = run;
                 int cnt = 0;
