@@ -1910,7 +1910,9 @@ __global__ __launch_bounds__(TT_THREADS, 5) void tier_tail_kernel(
                 // K keys (broadcast reads) and adds it up in LDS.  The 128-key sorting network costs 2.1 us even for an
                 // empty list (28 shuffle stages), this 0.5; from 1 024 keys on the network wins.
                 const uint32_t K = nchunks <= 1u ? FIN_CHUNK : nchunks == 2u ? 2u * FIN_CHUNK : 4u * FIN_CHUNK;
-                const uint32_t per = K * K / (uint32_t)TT_THREADS;                   // keys each thread looks at: 16 / 64 / 256
+                // keys each thread looks at: its share of the kept ones (in eights), at most 16 / 64 / 256
+                const uint32_t tpk = (uint32_t)TT_THREADS / K;                       // threads per key
+                const uint32_t per = min(K / tpk, ((total_kept + tpk - 1u) / tpk + 7u) & ~7u);
                 int *s_rank = reinterpret_cast<int *>(s_keys + K);                   // [K], then the sorted best
                 s_best = s_keys + K + K / 2u;
                 for (uint32_t p = nchunks * FIN_CHUNK + tid; p < K; p += TT_THREADS) s_keys[p] = ~0ull;     // (three chunks: pad to four)
@@ -1920,16 +1922,18 @@ __global__ __launch_bounds__(TT_THREADS, 5) void tier_tail_kernel(
                 const uint64_t mine = s_keys[t];
                 const uint64_t *from = s_keys + part * per;
                 uint32_t r = 0;
-                for (uint32_t j = 0; j < per; j += 8u) {
-                    uint64_t kk[8];
+                if (t < total_kept) {                                               // (the padding needs no place)
+                    for (uint32_t j = 0; j < per; j += 8u) {
+                        uint64_t kk[8];
 #pragma unroll
-                    for (uint32_t u = 0; u < 8u; ++u) kk[u] = from[j + u];
+                        for (uint32_t u = 0; u < 8u; ++u) kk[u] = from[j + u];
 #pragma unroll
-                    for (uint32_t u = 0; u < 8u; ++u) r += kk[u] < mine ? 1u : 0u;
+                        for (uint32_t u = 0; u < 8u; ++u) r += kk[u] < mine ? 1u : 0u;
+                    }
                 }
                 if (r != 0u) atomicAdd(&s_rank[t], (int)r);
                 __syncthreads();
-                if (tid < K && (uint32_t)s_rank[tid] < FIN_CHUNK) s_best[s_rank[tid]] = mine;      // (the ~0 padding shares its places: never read)
+                if (tid < total_kept && (uint32_t)s_rank[tid] < FIN_CHUNK) s_best[s_rank[tid]] = mine;
                 __syncthreads();
             } else {
                 best128_of_chunks<TT_WAVES>(s_keys, nchunks, tid);
