@@ -112,3 +112,31 @@ def test_more_rows_than_one_lds_chunk():
     rng = np.random.default_rng(12)
     gt = np.stack([workloads.crowd_boxes(rng, 128, 700)[0] for _ in range(2)])      # G = 700 > 512
     _check(anchors, gt)
+
+
+def test_zero_keys_posted_early_do_not_hide_later_matches():
+    """A wave of inverted anchors (negative area: it cannot cull, so it posts its IoU of -0 / +0 with EVERY row) sits in
+    the tile that is launched FIRST; the only anchors that overlap the ground truth sit in a tile launched after the
+    first resident blocks have finished, so their block starts from the keys that wave left.  A key of the value 0
+    (-0 is folded into +0) must read as "nothing to beat" there, and the late tile's anchors must win."""
+    import math
+    tiles = 4096
+    N = tiles * 256
+    mult = int(tiles * 0.6180339887) | 1
+    while math.gcd(mult, tiles) != 1:
+        mult += 2
+    first_tile = ((tiles - 1) * mult) % tiles                       # blockIdx 0 (see match_encode_kernel, GTBEST order)
+    late_tile = ((tiles - 1 - 3600) * mult) % tiles                 # blockIdx 3600: behind 1 536 resident blocks twice over
+    rng = np.random.default_rng(5)
+    F = np.float32
+    xy = rng.uniform(20000, 30000, (N, 2)).astype(F)                # everybody far away from the ground truth
+    wh = rng.uniform(8, 64, (N, 2)).astype(F)
+    anchors = np.concatenate([xy, xy + wh], 1)
+    anchors[first_tile * 256 + 64: first_tile * 256 + 128] = [1000.0, 0.0, 0.0, 1000.0]     # a whole wave with x0 > x1: area -1e6, unions < 0, IoU -0
+    gt = np.array([[[10, 10, 50, 50], [100, 100, 180, 160], [300, 20, 340, 90], [5, 200, 60, 260]]], F)
+    for g in range(4):                                              # near-matches in the late tile, two per row
+        x0, y0, x1, y1 = gt[0, g]
+        anchors[late_tile * 256 + 10 * g + 1] = [x0 + 2, y0 + 1, x1 + 3, y1 - 2]
+        anchors[late_tile * 256 + 10 * g + 70] = [x0 - 6, y0 + 4, x1 - 1, y1 + 5]
+    ra, ri = _check(anchors, gt, c_oracle.gt_best(anchors, gt, threads=8))
+    assert (ri[0] > 0.5).all() and (ra[0] // 256 == late_tile).all()
