@@ -36,6 +36,8 @@ def main():
         NAMES.update(FUSED)
     else:
         BB.set_nms_fused_tail(False)
+    if os.environ.get('ODBOX_STAMPS_TIER'):                   # ODBOX_STAMPS_TIER=0: no score tier, the single plain pass (pass 2's kernels)
+        BB.set_nms_tier(int(os.environ['ODBOX_STAMPS_TIER']))
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     c = workloads.CONFIGS[5]
     anchors = A.generate_anchors(A.AnchorsConfig(), c['S'])
