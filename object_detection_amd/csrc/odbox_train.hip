@@ -388,7 +388,8 @@ __device__ __forceinline__ TileMatch match_tile(const float4 *__restrict__ ancho
                     bool any_reach = false;
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        const float cur = __uint_as_float(reinterpret_cast<const uint32_t *>(&row_at(g[r]).key)[1] & 0x7fffffffu);
+                        // (|x|: the sign bit is the ordered form's marker of a value >= 0; as a source modifier it costs nothing)
+                        const float cur = fabsf(__uint_as_float(reinterpret_cast<const uint32_t *>(&row_at(g[r]).key)[1]));
                         reach[r] = ia[r] > 0.0f && q[r] * BAND_HI >= cur;
                         any_reach = any_reach || reach[r];
                     }
